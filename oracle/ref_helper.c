@@ -1,0 +1,320 @@
+// oracle/ref_helper.c -- TEST INFRASTRUCTURE, not product code.
+//
+// Flat-array (ctypes-friendly) wrapper around the UNCHANGED reference CHOLMOD
+// built by oracle/build_ref.sh into oracle/_ref/libcholmod_ref.so.  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
+// It drives the reference exactly the way its own callers do:
+//   analyze    : cholmod_l_analyze_p            (CHOLMOD/Cholesky/cholmod_analyze.c:121,384)
+//   permute    : the ptranspose sequence of     CHOLMOD/Cholesky/cholmod_factorize.c:181-251
+//   factorize  : cholmod_l_super_numeric(S,..)  (CHOLMOD/Supernodal/cholmod_super_numeric.c:100,
+//                called as in CHOLMOD/Tcov/t_raw_factor.c:239)
+//   solve      : cholmod_l_super_lsolve/ltsolve (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153)
+//                and cholmod_l_solve            (CHOLMOD/Cholesky/cholmod_solve.c:99)
+
+#include "cholmod.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+typedef struct
+{
+    cholmod_common cm ;
+    cholmod_sparse *A ;     // user matrix (any stype)
+    cholmod_sparse *S ;     // tril (P A P'), what super_numeric receives
+    cholmod_factor *L ;
+    double t_analyze, t_factor, t_solve ;
+    int last_status ;
+} ref_ctx ;
+
+static void quiet_handler (int status, const char *file, int line, const char *msg)
+{
+    (void) status ; (void) file ; (void) line ; (void) msg ;
+}
+
+void *ref_new (void)
+{
+    ref_ctx *h = calloc (1, sizeof (ref_ctx)) ;
+    cholmod_l_start (&h->cm) ;
+    h->cm.useGPU = 0 ;
+    h->cm.error_handler = quiet_handler ;
+    h->cm.supernodal = CHOLMOD_SUPERNODAL ;
+    return h ;
+}
+
+void ref_free (void *hv)
+{
+    ref_ctx *h = hv ;
+    if (!h) return ;
+    if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    cholmod_l_free_sparse (&h->A, &h->cm) ;
+    cholmod_l_free_factor (&h->L, &h->cm) ;
+    cholmod_l_finish (&h->cm) ;
+    free (h) ;
+}
+
+int ref_nthreads (void *hv) { return ((ref_ctx *) hv)->cm.nthreads_max ; }
+void ref_set_nthreads (void *hv, int nt) { ((ref_ctx *) hv)->cm.nthreads_max = nt ; }
+
+// xtype: 1 real, 2 complex (interleaved re,im).  Ax may be NULL only if nnz==0.
+int ref_load_matrix (void *hv, int64_t n, const int64_t *Ap, const int64_t *Ai,
+    const double *Ax, int xtype, int stype)
+{
+    ref_ctx *h = hv ;
+    if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    h->S = NULL ;
+    cholmod_l_free_sparse (&h->A, &h->cm) ;
+    int64_t nz = Ap [n] ;
+    h->A = cholmod_l_allocate_sparse (n, n, nz > 0 ? nz : 1, /*sorted*/ 1,
+        /*packed*/ 1, stype, xtype + CHOLMOD_DOUBLE, &h->cm) ;
+    if (!h->A) return -1 ;
+    memcpy (h->A->p, Ap, (n+1) * sizeof (int64_t)) ;
+    memcpy (h->A->i, Ai, nz * sizeof (int64_t)) ;
+    memcpy (h->A->x, Ax, nz * sizeof (double) * (xtype == CHOLMOD_COMPLEX ? 2 : 1)) ;
+    return 0 ;
+}
+
+// read one of the reference's own fixture files (.tri / .mtx); returns 0 on success
+int ref_read_matrix (void *hv, const char *path)
+{
+    ref_ctx *h = hv ;
+    FILE *f = fopen (path, "r") ;
+    if (!f) return -1 ;
+    if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    h->S = NULL ;
+    cholmod_l_free_sparse (&h->A, &h->cm) ;
+    h->A = cholmod_l_read_sparse2 (f, CHOLMOD_DOUBLE, &h->cm) ;
+    fclose (f) ;
+    if (!h->A) return -2 ;
+    if (h->A->xtype == CHOLMOD_PATTERN)
+    {
+        // same convention as the demo (cholmod_dl_demo.c: pattern -> values)
+        return -3 ;
+    }
+    if (h->A->xtype == CHOLMOD_ZOMPLEX)
+    {
+        cholmod_l_sparse_xtype (CHOLMOD_COMPLEX + CHOLMOD_DOUBLE, h->A, &h->cm) ;
+    }
+    cholmod_l_sort (h->A, &h->cm) ;
+    return 0 ;
+}
+
+// iout: n, nnz, xtype, stype
+void ref_matrix_info (void *hv, int64_t *iout)
+{
+    ref_ctx *h = hv ;
+    iout [0] = h->A->nrow ;
+    iout [1] = cholmod_l_nnz (h->A, &h->cm) ;
+    iout [2] = h->A->xtype ;
+    iout [3] = h->A->stype ;
+    iout [4] = h->A->ncol ;
+}
+
+void ref_get_matrix (void *hv, int64_t *Ap, int64_t *Ai, double *Ax)
+{
+    ref_ctx *h = hv ;
+    cholmod_sparse *A = h->A ;
+    int64_t n = A->ncol, *p = A->p, *ii = A->i, *nzv = A->nz ;
+    double *x = A->x ;
+    int E = (A->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    int64_t q = 0 ;
+    for (int64_t j = 0 ; j < n ; j++)
+    {
+        Ap [j] = q ;
+        int64_t pend = A->packed ? p [j+1] : p [j] + nzv [j] ;
+        for (int64_t k = p [j] ; k < pend ; k++)
+        {
+            Ai [q] = ii [k] ;
+            for (int e = 0 ; e < E ; e++) Ax [E*q+e] = x [E*k+e] ;
+            q++ ;
+        }
+    }
+    Ap [n] = q ;
+}
+
+// ordering: CHOLMOD_NATURAL 0, GIVEN 1, AMD 2, METIS 3, NESDIS 4; -1 = default strategy
+// supernodal: CHOLMOD_SIMPLICIAL 0 / AUTO 1 / SUPERNODAL 2
+int ref_analyze (void *hv, int ordering, const int64_t *perm, int supernodal)
+{
+    ref_ctx *h = hv ;
+    cholmod_l_free_factor (&h->L, &h->cm) ;
+    h->cm.supernodal = supernodal ;
+    if (ordering >= 0)
+    {
+        h->cm.nmethods = 1 ;
+        h->cm.method [0].ordering = ordering ;
+        h->cm.postorder = 1 ;
+    }
+    else
+    {
+        h->cm.nmethods = 0 ;
+    }
+    double t = SuiteSparse_time ( ) ;
+    h->L = cholmod_l_analyze_p (h->A, (int64_t *) perm, NULL, 0, &h->cm) ;
+    h->t_analyze = SuiteSparse_time ( ) - t ;
+    h->last_status = h->cm.status ;
+    return (h->L == NULL) ? -1 : h->cm.status ;
+}
+
+// iout[16]: n nsuper ssize xsize maxcsize maxesize ordering is_super xtype minor is_ll status nthreads
+// dout[8]:  fl lnz anz t_analyze t_factor t_solve
+void ref_info (void *hv, int64_t *iout, double *dout)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    memset (iout, 0, 16 * sizeof (int64_t)) ;
+    if (L)
+    {
+        iout [0] = L->n ; iout [1] = L->nsuper ; iout [2] = L->ssize ;
+        iout [3] = L->xsize ; iout [4] = L->maxcsize ; iout [5] = L->maxesize ;
+        iout [6] = L->ordering ; iout [7] = L->is_super ; iout [8] = L->xtype ;
+        iout [9] = L->minor ; iout [10] = L->is_ll ;
+    }
+    iout [11] = h->last_status ;
+    iout [12] = h->cm.nthreads_max ;
+    dout [0] = h->cm.fl ; dout [1] = h->cm.lnz ; dout [2] = h->cm.anz ;
+    dout [3] = h->t_analyze ; dout [4] = h->t_factor ; dout [5] = h->t_solve ;
+}
+
+void ref_get_symbolic (void *hv, int64_t *Perm, int64_t *ColCount,
+    int64_t *Super, int64_t *Lpi, int64_t *Lpx, int64_t *Ls)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    memcpy (Perm, L->Perm, L->n * sizeof (int64_t)) ;
+    memcpy (ColCount, L->ColCount, L->n * sizeof (int64_t)) ;
+    if (L->is_super)
+    {
+        memcpy (Super, L->super, (L->nsuper+1) * sizeof (int64_t)) ;
+        memcpy (Lpi, L->pi, (L->nsuper+1) * sizeof (int64_t)) ;
+        memcpy (Lpx, L->px, (L->nsuper+1) * sizeof (int64_t)) ;
+        memcpy (Ls, L->s, L->ssize * sizeof (int64_t)) ;
+    }
+}
+
+// S = tril (P A P'), the ptranspose sequence of cholmod_factorize.c:181-251
+int64_t ref_permute (void *hv)
+{
+    ref_ctx *h = hv ;
+    cholmod_sparse *A = h->A, *A1 = NULL, *A2 = NULL ;
+    cholmod_factor *L = h->L ;
+    if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    h->S = NULL ;
+    if (A->stype == 0) return -1 ;
+    if (L->ordering == CHOLMOD_NATURAL)
+    {
+        if (A->stype > 0) { A1 = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, &h->cm) ; h->S = A1 ; }
+        else h->S = A ;
+    }
+    else if (A->stype > 0)
+    {
+        A1 = cholmod_l_ptranspose (A, 2, L->Perm, NULL, 0, &h->cm) ;
+        h->S = A1 ;
+    }
+    else
+    {
+        A2 = cholmod_l_ptranspose (A, 2, L->Perm, NULL, 0, &h->cm) ;
+        A1 = cholmod_l_ptranspose (A2, 2, NULL, NULL, 0, &h->cm) ;
+        cholmod_l_free_sparse (&A2, &h->cm) ;
+        h->S = A1 ;
+    }
+    if (!h->S) return -2 ;
+    return cholmod_l_nnz (h->S, &h->cm) ;
+}
+
+void ref_get_S (void *hv, int64_t *Sp, int64_t *Si, double *Sx)
+{
+    ref_ctx *h = hv ;
+    cholmod_sparse *Asave = h->A ;
+    h->A = h->S ;
+    ref_get_matrix (hv, Sp, Si, Sx) ;
+    h->A = Asave ;
+}
+
+// numeric factorization through the reference CPU worker; returns Common->status
+// (0 OK, 1 NOT_POSDEF, <0 error).  Needs ref_permute first.
+int ref_factorize (void *hv, double beta_re, int quick_return_if_not_posdef)
+{
+    ref_ctx *h = hv ;
+    double beta [2] = { beta_re, 0 } ;
+    h->cm.quick_return_if_not_posdef = quick_return_if_not_posdef ;
+    double t = SuiteSparse_time ( ) ;
+    int ok = cholmod_l_super_numeric (h->S, NULL, beta, h->L, &h->cm) ;
+    h->t_factor = SuiteSparse_time ( ) - t ;
+    h->last_status = h->cm.status ;
+    return ok ? h->cm.status : (h->cm.status < 0 ? h->cm.status : -99) ;
+}
+
+// whole cholmod_l_factorize (permute + numeric), as the demo times it
+int ref_factorize_full (void *hv, double beta_re)
+{
+    ref_ctx *h = hv ;
+    double beta [2] = { beta_re, 0 } ;
+    double t = SuiteSparse_time ( ) ;
+    cholmod_l_factorize_p (h->A, beta, NULL, 0, h->L, &h->cm) ;
+    h->t_factor = SuiteSparse_time ( ) - t ;
+    h->last_status = h->cm.status ;
+    return h->cm.status ;
+}
+
+void ref_get_Lx (void *hv, double *Lx)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    int E = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    memcpy (Lx, L->x, L->xsize * E * sizeof (double)) ;
+}
+
+// overwrite the numeric values of the reference factor (drop-in check: the
+// reference's own solve runs on a factor computed elsewhere)
+int ref_set_Lx (void *hv, const double *Lx, int64_t minor)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    if (L->xtype == CHOLMOD_PATTERN) return -1 ;
+    int E = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    memcpy (L->x, Lx, L->xsize * E * sizeof (double)) ;
+    L->minor = minor ;
+    return 0 ;
+}
+
+// X (n x nrhs, ld d, xtype of L) is overwritten: lower=1 -> L\X, lower=0 -> L'\X
+int ref_super_solve (void *hv, int lower, int64_t nrhs, double *Xx, int64_t d)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    int E = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    cholmod_dense X ;
+    memset (&X, 0, sizeof (X)) ;
+    X.nrow = L->n ; X.ncol = nrhs ; X.d = d ; X.nzmax = d * nrhs ;
+    X.x = Xx ; X.xtype = L->xtype ; X.dtype = CHOLMOD_DOUBLE ;
+    cholmod_dense *Ew = cholmod_l_allocate_dense (nrhs, L->maxesize, nrhs,
+        L->xtype + CHOLMOD_DOUBLE, &h->cm) ;
+    if (!Ew) return -1 ;
+    (void) E ;
+    double t = SuiteSparse_time ( ) ;
+    int ok = lower ? cholmod_l_super_lsolve (L, &X, Ew, &h->cm)
+                   : cholmod_l_super_ltsolve (L, &X, Ew, &h->cm) ;
+    h->t_solve = SuiteSparse_time ( ) - t ;
+    cholmod_l_free_dense (&Ew, &h->cm) ;
+    return ok ? 0 : -2 ;
+}
+
+// X = A\B through cholmod_l_solve (CHOLMOD_A); B, X: n x nrhs, ld n, xtype of L
+int ref_solve (void *hv, int64_t nrhs, const double *Bx, double *Xx)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    int E = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    cholmod_dense B ;
+    memset (&B, 0, sizeof (B)) ;
+    B.nrow = L->n ; B.ncol = nrhs ; B.d = L->n ; B.nzmax = L->n * nrhs ;
+    B.x = (void *) Bx ; B.xtype = L->xtype ; B.dtype = CHOLMOD_DOUBLE ;
+    double t = SuiteSparse_time ( ) ;
+    cholmod_dense *X = cholmod_l_solve (CHOLMOD_A, L, &B, &h->cm) ;
+    h->t_solve = SuiteSparse_time ( ) - t ;
+    if (!X) return -1 ;
+    memcpy (Xx, X->x, L->n * nrhs * E * sizeof (double)) ;
+    cholmod_l_free_dense (&X, &h->cm) ;
+    return 0 ;
+}

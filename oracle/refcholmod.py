@@ -1,0 +1,233 @@
+"""oracle/refcholmod.py -- TEST INFRASTRUCTURE, not product code.
+
+ctypes binding of oracle/_ref/libref_helper.so (the unchanged reference CHOLMOD
+5.3.0 CPU path built by oracle/build_ref.sh).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+ORDERINGS = {"natural": 0, "given": 1, "amd": 2, "metis": 3, "nesdis": 4, "default": -1}
+ORDERING_NAMES = {0: "natural", 1: "given", 2: "amd", 3: "metis", 4: "nesdis", 5: "colamd", 6: "postordered"}
+
+
+def available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_helper.so")) and \
+        os.path.exists("/opt/conda/lib/libmkl_rt.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        # MKL's default threading layer is Intel OpenMP; CHOLMOD is built with libgomp
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_helper.so"), mode=C.RTLD_GLOBAL)
+        L.ref_new.restype = C.c_void_p
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_nthreads.argtypes = [C.c_void_p]
+        L.ref_set_nthreads.argtypes = [C.c_void_p, C.c_int]
+        L.ref_load_matrix.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, f64p, C.c_int, C.c_int]
+        L.ref_read_matrix.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_matrix_info.argtypes = [C.c_void_p, i64p]
+        L.ref_get_matrix.argtypes = [C.c_void_p, i64p, i64p, f64p]
+        L.ref_analyze.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.ref_info.argtypes = [C.c_void_p, i64p, f64p]
+        L.ref_get_symbolic.argtypes = [C.c_void_p, i64p, i64p, i64p, i64p, i64p, i64p]
+        L.ref_permute.argtypes = [C.c_void_p]
+        L.ref_permute.restype = C.c_int64
+        L.ref_get_S.argtypes = [C.c_void_p, i64p, i64p, f64p]
+        L.ref_factorize.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.ref_factorize_full.argtypes = [C.c_void_p, C.c_double]
+        L.ref_get_Lx.argtypes = [C.c_void_p, f64p]
+        L.ref_set_Lx.argtypes = [C.c_void_p, f64p, C.c_int64]
+        L.ref_super_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, f64p, C.c_int64]
+        L.ref_solve.argtypes = [C.c_void_p, C.c_int64, f64p, f64p]
+        _LIB = L
+    return _LIB
+
+
+class RefCholmod:
+    """One cholmod_common + matrix + factor of the reference library."""
+
+    def __init__(self, nthreads=None):
+        self.L = lib()
+        self.h = self.L.ref_new()
+        if nthreads is not None:
+            self.L.ref_set_nthreads(self.h, int(nthreads))
+        self.n = 0
+        self.xtype = 1
+
+    def close(self):
+        if self.h:
+            self.L.ref_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nthreads(self):
+        return self.L.ref_nthreads(self.h)
+
+    # ---- matrix ----
+    def load(self, n, Ap, Ai, Ax, stype=-1):
+        Ap = np.ascontiguousarray(Ap, dtype=np.int64)
+        Ai = np.ascontiguousarray(Ai, dtype=np.int64)
+        cplx = np.iscomplexobj(Ax)
+        Axf = np.ascontiguousarray(Ax, dtype=np.complex128).view(np.float64) if cplx \
+            else np.ascontiguousarray(Ax, dtype=np.float64)
+        if Axf.size == 0:
+            Axf = np.zeros(2)
+        rc = self.L.ref_load_matrix(self.h, n, Ap, Ai, Axf, 2 if cplx else 1, stype)
+        if rc != 0:
+            raise RuntimeError("ref_load_matrix failed")
+        self.n = n
+        self.xtype = 2 if cplx else 1
+
+    def read(self, path):
+        rc = self.L.ref_read_matrix(self.h, path.encode())
+        if rc != 0:
+            raise RuntimeError(f"ref_read_matrix({path}) -> {rc}")
+        info = np.zeros(8, dtype=np.int64)
+        self.L.ref_matrix_info(self.h, info)
+        self.n = int(info[0])
+        self.xtype = int(info[2])
+        return self.matrix()
+
+    def matrix(self):
+        info = np.zeros(8, dtype=np.int64)
+        self.L.ref_matrix_info(self.h, info)
+        n, nnz, xtype, stype, ncol = (int(v) for v in info[:5])
+        Ap = np.zeros(ncol + 1, dtype=np.int64)
+        Ai = np.zeros(max(nnz, 1), dtype=np.int64)
+        Ax = np.zeros(max(nnz, 1) * (2 if xtype == 2 else 1))
+        self.L.ref_get_matrix(self.h, Ap, Ai, Ax)
+        Ai = Ai[:nnz]
+        Ax = Ax[:nnz * (2 if xtype == 2 else 1)]
+        if xtype == 2:
+            Ax = Ax.view(np.complex128)
+        return dict(n=n, ncol=ncol, Ap=Ap, Ai=Ai, Ax=Ax, stype=stype, xtype=xtype)
+
+    # ---- analyze ----
+    def analyze(self, ordering="metis", perm=None, supernodal=2):
+        code = ORDERINGS[ordering] if isinstance(ordering, str) else int(ordering)
+        p = None
+        if perm is not None:
+            self._perm = np.ascontiguousarray(perm, dtype=np.int64)
+            p = self._perm.ctypes.data_as(C.c_void_p)
+            code = 1
+        rc = self.L.ref_analyze(self.h, code, p, supernodal)
+        if rc < 0:
+            raise RuntimeError(f"ref_analyze failed: {rc}")
+        return self.info()
+
+    def info(self):
+        io = np.zeros(16, dtype=np.int64)
+        do = np.zeros(8)
+        self.L.ref_info(self.h, io, do)
+        keys = ["n", "nsuper", "ssize", "xsize", "maxcsize", "maxesize", "ordering", "is_super",
+                "xtype", "minor", "is_ll", "status", "nthreads"]
+        d = {k: int(v) for k, v in zip(keys, io)}
+        d.update(fl=do[0], lnz=do[1], anz=do[2], t_analyze=do[3], t_factor=do[4], t_solve=do[5])
+        d["ordering_name"] = ORDERING_NAMES.get(d["ordering"], "?")
+        return d
+
+    def symbolic(self):
+        inf = self.info()
+        n, ns, ss = inf["n"], inf["nsuper"], inf["ssize"]
+        Perm = np.zeros(n, dtype=np.int64)
+        ColCount = np.zeros(n, dtype=np.int64)
+        Super = np.zeros(ns + 1, dtype=np.int64)
+        Lpi = np.zeros(ns + 1, dtype=np.int64)
+        Lpx = np.zeros(ns + 1, dtype=np.int64)
+        Ls = np.zeros(max(ss, 1), dtype=np.int64)
+        self.L.ref_get_symbolic(self.h, Perm, ColCount, Super, Lpi, Lpx, Ls)
+        return dict(n=n, nsuper=ns, ssize=ss, xsize=inf["xsize"], maxcsize=inf["maxcsize"],
+                    maxesize=inf["maxesize"], Perm=Perm, ColCount=ColCount, Super=Super,
+                    Lpi=Lpi, Lpx=Lpx, Ls=Ls[:ss])
+
+    def permuted(self):
+        """S = tril(P A P') exactly as cholmod_factorize builds it."""
+        nnz = self.L.ref_permute(self.h)
+        if nnz < 0:
+            raise RuntimeError("ref_permute failed")
+        E = 2 if self.xtype == 2 else 1
+        Sp = np.zeros(self.n + 1, dtype=np.int64)
+        Si = np.zeros(max(nnz, 1), dtype=np.int64)
+        Sx = np.zeros(max(nnz, 1) * E)
+        self.L.ref_get_S(self.h, Sp, Si, Sx)
+        Si = Si[:nnz]
+        Sx = Sx[:nnz * E]
+        if E == 2:
+            Sx = Sx.view(np.complex128)
+        return Sp, Si, Sx
+
+    # ---- numeric ----
+    def factorize(self, beta=0.0, quick_return=False):
+        """reference cholmod_l_super_numeric on S; returns Common->status."""
+        return self.L.ref_factorize(self.h, float(beta), int(bool(quick_return)))
+
+    def factorize_full(self, beta=0.0):
+        return self.L.ref_factorize_full(self.h, float(beta))
+
+    def Lx(self):
+        inf = self.info()
+        E = 2 if inf["xtype"] == 2 else 1
+        out = np.zeros(inf["xsize"] * E)
+        self.L.ref_get_Lx(self.h, out)
+        return out.view(np.complex128) if E == 2 else out
+
+    def set_Lx(self, Lx, minor=None):
+        inf = self.info()
+        Lxf = np.ascontiguousarray(Lx)
+        if np.iscomplexobj(Lxf):
+            Lxf = Lxf.astype(np.complex128).view(np.float64)
+        Lxf = np.ascontiguousarray(Lxf, dtype=np.float64)
+        rc = self.L.ref_set_Lx(self.h, Lxf, inf["n"] if minor is None else int(minor))
+        if rc != 0:
+            raise RuntimeError("ref_set_Lx failed")
+
+    def _as_f64(self, X):
+        inf = self.info()
+        if inf["xtype"] == 2:
+            Xc = np.asfortranarray(X, dtype=np.complex128)
+            return Xc, np.ascontiguousarray(Xc.T).view(np.float64).reshape(-1)
+        Xr = np.asfortranarray(X, dtype=np.float64)
+        return Xr, np.ascontiguousarray(Xr.T).reshape(-1)
+
+    def super_solve(self, X, lower=True):
+        """L\\X (lower) or L^H\\X; X is n x nrhs; returns the solution (same shape)."""
+        X = np.atleast_2d(np.asarray(X).T).T if np.asarray(X).ndim == 1 else np.asarray(X)
+        n, nrhs = X.shape
+        _, flat = self._as_f64(X)
+        flat = flat.copy()
+        rc = self.L.ref_super_solve(self.h, 1 if lower else 0, nrhs, flat, n)
+        if rc != 0:
+            raise RuntimeError("ref_super_solve failed")
+        if self.info()["xtype"] == 2:
+            return flat.view(np.complex128).reshape(nrhs, n).T.copy()
+        return flat.reshape(nrhs, n).T.copy()
+
+    def solve(self, B):
+        B = np.asarray(B)
+        if B.ndim == 1:
+            B = B[:, None]
+        n, nrhs = B.shape
+        _, flat = self._as_f64(B)
+        out = np.zeros_like(flat)
+        rc = self.L.ref_solve(self.h, nrhs, flat, out)
+        if rc != 0:
+            raise RuntimeError("ref_solve failed")
+        if self.info()["xtype"] == 2:
+            return out.view(np.complex128).reshape(nrhs, n).T.copy()
+        return out.reshape(nrhs, n).T.copy()
