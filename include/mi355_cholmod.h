@@ -1,0 +1,132 @@
+/* mi355_cholmod.h -- C ABI of the MI355X-native supernodal numeric engine.
+ *
+ * Drop-in boundary for the numeric phase of CHOLMOD's supernodal Cholesky
+ * (int64 indices, double precision).  Plain pointers and sizes only; every array
+ * is laid out exactly like the corresponding cholmod_factor / cholmod_sparse field
+ * (CHOLMOD/Include/cholmod.h:1584-1651, :1168-1206), so a CHOLMOD build can pass its
+ * own arrays straight through (INTEGRATION.md shows the dispatch a maintainer adds
+ * at CHOLMOD/Supernodal/cholmod_super_numeric.c:295-322 and
+ * CHOLMOD/Supernodal/cholmod_super_solve.c:114-131,215-232).
+ *
+ * All functions return MI355_OK (0) or a negative MI355_* code; the CHOLMOD-style
+ * status (Common->status, cholmod.h:833-840) is reported separately where the
+ * reference would set it.  mi355_last_error() gives a message for the calling thread.
+ * A factor handle is not re-entrant (like a cholmod_common); distinct handles may be
+ * used from distinct threads.
+ */
+#ifndef MI355_CHOLMOD_H
+#define MI355_CHOLMOD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes */
+#define MI355_OK              0
+#define MI355_INVALID        (-4)   /* = CHOLMOD_INVALID       */
+#define MI355_OUT_OF_MEMORY  (-2)   /* = CHOLMOD_OUT_OF_MEMORY */
+#define MI355_TOO_LARGE      (-3)   /* = CHOLMOD_TOO_LARGE     */
+#define MI355_GPU_PROBLEM    (-5)   /* = CHOLMOD_GPU_PROBLEM   */
+#define MI355_NOT_INSTALLED  (-1)   /* = CHOLMOD_NOT_INSTALLED (xtype/stype routed to the CPU worker) */
+
+/* CHOLMOD status values reported through *status */
+#define MI355_STATUS_OK          0  /* CHOLMOD_OK         */
+#define MI355_STATUS_NOT_POSDEF  1  /* CHOLMOD_NOT_POSDEF */
+
+/* xtype values (cholmod.h:134-137) */
+#define MI355_REAL     1
+#define MI355_COMPLEX  2
+#define MI355_ZOMPLEX  3
+
+typedef struct mi355_factor_s mi355_factor;   /* opaque: device-resident factor + schedule */
+
+/* ---- lifecycle: replaces cholmod_l_gpu_probe / _allocate / _deallocate / _start / _end
+ *      (CHOLMOD/Include/cholmod.h:4148-4175; CHOLMOD/GPU/cholmod_gpu.c:148,426,187,234,319) */
+
+/* number of usable MI355X-class devices visible to this process (0: none).
+ * replaces cholmod_l_gpu_probe (cholmod_gpu.c:148). */
+int mi355_probe(void);
+
+/* message of the last failing call on this thread ("" if none) */
+const char *mi355_last_error(void);
+
+/* Build the device-side image of a supernodal SYMBOLIC factor: uploads
+ * Super/Lpi/Lpx/Ls, replays the descendant lists into the level schedule, builds
+ * all relative maps on the device, allocates Lx (xsize entries) in HBM.
+ * Arrays are cholmod_factor's super/pi/px/s (cholmod.h:1604-1651); they are copied.
+ * xtype: MI355_REAL (complex factors: MI355_NOT_INSTALLED until the cd_ kernels land).
+ * replaces gpu_init + cholmod_l_gpu_allocate (CHOLMOD/GPU/t_cholmod_gpu.c:84-160,
+ * cholmod_gpu.c:426-543) and the per-supernode Map/RelativeMap kernels. */
+int mi355_factor_create(int xtype, int64_t n, int64_t nsuper,
+                        const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                        const int64_t *Ls, int64_t ssize, int64_t xsize,
+                        int device, mi355_factor **handle);
+
+/* replaces cholmod_l_gpu_deallocate / gpu_end (cholmod_gpu.c:187,319) */
+int mi355_factor_free(mi355_factor *handle);
+
+/* ---- numeric factorization: replaces {rd}_cholmod_super_numeric_worker
+ *      (CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:133-1279) */
+
+/* Stage the matrix S = tril(P A P') (stype < 0; cholmod_sparse p/i/nz/x, packed when
+ * Anz == NULL) in HBM.  Host pointers; copied. */
+int mi355_factor_set_matrix(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
+                            const int64_t *Anz, const double *Ax);
+
+/* Factorize the staged matrix: Lx (device) <- chol(S + beta*I).  *status receives
+ * CHOLMOD_OK or CHOLMOD_NOT_POSDEF and *minor the reference's L->minor (n if positive
+ * definite), with the reference's zeroing/repeat-supernode semantics
+ * (worker :1084-1146).  Inputs and outputs stay resident in HBM. */
+int mi355_factor_numeric(mi355_factor *handle, double beta_re,
+                         int quick_return_if_not_posdef, int64_t *minor, int *status);
+
+/* Copy the numeric factor to the host array L->x (xsize doubles). */
+int mi355_factor_get_Lx(mi355_factor *handle, double *Lx);
+
+/* One call = cholmod_super_numeric's numeric part for (int64, double, real, stype<0):
+ * set_matrix + numeric + get_Lx on an existing handle (create it once per analyze). */
+int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
+                        const int64_t *Anz, const double *Ax, double beta_re,
+                        int quick_return_if_not_posdef, double *Lx,
+                        int64_t *minor, int *status);
+
+/* ---- supernodal triangular solves: replace cholmod_l_super_lsolve / _ltsolve
+ *      (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153; workers
+ *      t_cholmod_super_solve_worker.c:20-303,309-580).  X is n x nrhs, column-major,
+ *      leading dimension d >= n, host memory, overwritten with L\X or L'\X.
+ *      No workspace E is needed. */
+int mi355_super_lsolve(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);
+int mi355_super_ltsolve(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);
+
+/* device-resident variants (X already in HBM, ld d): used when the caller keeps the
+ * right-hand sides on the device between the forward and the backward sweep. */
+int mi355_super_lsolve_dev(mi355_factor *handle, int64_t nrhs, double *X_dev, int64_t d);
+int mi355_super_ltsolve_dev(mi355_factor *handle, int64_t nrhs, double *X_dev, int64_t d);
+
+/* ---- instrumentation: replaces the -DBLAS_TIMER counters
+ *      (worker :246-266,:763-811; Common->cholmod_gpu_*_time, cholmod.h:966-986) */
+
+/* Device pointer of Lx (for callers that consume the factor on the device). */
+double *mi355_factor_device_Lx(mi355_factor *handle);
+
+/* profile != 0: the next numeric calls bracket every launch with HIP events on the
+ * engine's stream. */
+int mi355_factor_set_profile(mi355_factor *handle, int profile);
+
+/* out[0..15]: 0 total ms of the last numeric call (events on the engine stream)
+ *             1 ms in update/trailing/trsm GEMM launches   2 number of GEMM launches
+ *             3 ms in POTRF launches                       4 number of POTRF launches
+ *             5 ms in assembly (memset + A scatter)        6 executed GEMM flops
+ *             7 executed panel flops                       8 assembly bytes (sum ndrow1*ndrow2*8)
+ *             9 number of (d,s) update pairs              10 number of levels
+ *            11 relative-map entries                      12 block-inverse entries
+ *            13 ms of the last solve call                 14 GEMM tiles launched
+ *            15 reserved */
+int mi355_factor_get_stats(mi355_factor *handle, double *out16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_CHOLMOD_H */

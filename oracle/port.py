@@ -67,7 +67,7 @@ def super_solve(sym, Lx, X, lower=True):
         X = X[:, None]
     n, nrhs = X.shape
     dt = np.complex128 if E == 2 else np.float64
-    Xt = np.ascontiguousarray(np.asarray(X, dtype=dt).T)        # nrhs x n  == col-major n x nrhs
+    Xt = np.array(np.asarray(X, dtype=dt).T, order="C", copy=True)   # nrhs x n == col-major n x nrhs (own copy)
     flat = Xt.view(np.float64).reshape(-1)
     f = lib().oracle_super_lsolve if lower else lib().oracle_super_ltsolve
     Ls = np.ascontiguousarray(sym["Ls"], dtype=np.int64)

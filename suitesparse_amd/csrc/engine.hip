@@ -1,0 +1,534 @@
+// engine.hip -- device engine + C ABI (include/mi355_cholmod.h) of the MI355X-native
+// supernodal numeric factorization / solve.  gfx950 only.
+//
+// Host side mirrors the reference wrapper cholmod_super_numeric
+// (CHOLMOD/Supernodal/cholmod_super_numeric.c:100-335): validate, build SuperMap,
+// run the worker, report status/minor -- except that the worker is the level-scheduled
+// device pipeline of schedule.hpp instead of the sequential CPU loop
+// (t_cholmod_super_numeric_worker.c:335-1266).  There is NO CPU fallback in this
+// library: without a usable device every entry point fails with MI355_GPU_PROBLEM.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/mi355_cholmod.h"
+#include "schedule.hpp"
+#include "kernels.hip.hpp"
+#include "solve_kernels.hip.hpp"
+
+using namespace mi355;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            char b_[512];                                                                 \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? MI355_OUT_OF_MEMORY : MI355_GPU_PROBLEM, b_); \
+        }                                                                                 \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const T *src, size_t count, hipStream_t st)
+    {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        e = hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    }
+};
+
+// device image of one Schedule
+struct DeviceSchedule {
+    Schedule sched;
+    DevBuf<GemmTask> gemm;
+    DevBuf<PotrfTask> potrf;
+    DevBuf<int32_t> relmap;
+};
+
+}  // namespace
+
+struct mi355_factor_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int xtype = MI355_REAL;
+    // host copy of the symbolic factor
+    std::vector<int64_t> Super, Lpi, Lpx, Ls;
+    Symbolic sym;
+    // device
+    DevBuf<double> Lx, Dinv;
+    DevBuf<int32_t> dLs, dSupermap;
+    DevBuf<int64_t> dSuper, dLpi, dLpx;
+    DevBuf<int> info;           // nsuper + 2 (first-failure scratch at [nsuper], [nsuper+1])
+    DeviceSchedule full;
+    // staged matrix
+    DevBuf<int64_t> Ap, Ai, Anz;
+    DevBuf<double> Ax;
+    bool have_A = false, A_unpacked = false;
+    bool numeric_ok = false;    // a positive-definite factor is resident
+    int64_t minor = 0;
+    // instrumentation
+    int profile = 0;
+    double st_total = 0, st_gemm = 0, st_potrf = 0, st_asm = 0, st_solve = 0;
+    double st_ngemm = 0, st_npotrf = 0, st_tiles = 0;
+};
+
+namespace {
+
+__global__ void k_first_info(int64_t nsuper, const int *__restrict__ info, int *__restrict__ out)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nsuper && info[s] != 0) atomicMin(out, (int)s);
+}
+
+int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
+{
+    Schedule &S = D.sched;
+    HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
+    HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
+    HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
+    if (S.relmap_size > 0) {
+        std::vector<RelmapPair> rp(S.pairs.size());
+        for (size_t i = 0; i < rp.size(); i++) {
+            rp[i].ls_src = S.pairs[i].ls_src; rp[i].ls_dst = S.pairs[i].ls_dst;
+            rp[i].rm_off = S.pairs[i].rm_off; rp[i].nsrow = S.pairs[i].nsrow; rp[i].pad = 0;
+        }
+        DevBuf<RelmapPair> drp;
+        HIP_TRY(drp.upload(rp.data(), rp.size(), F->stream));
+        DevBuf<int> derr;
+        HIP_TRY(derr.alloc(1));
+        HIP_TRY(hipMemsetAsync(derr.p, 0, sizeof(int), F->stream));
+        const int64_t total = S.relmap_size;
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(k_relmap, dim3(grid), dim3(256), 0, F->stream, total, (int64_t)rp.size(),
+                           drp.p, F->dLs.p, D.relmap.p, derr.p);
+        HIP_TRY(hipGetLastError());
+        int herr = 0;
+        HIP_TRY(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, F->stream));
+        HIP_TRY(hipStreamSynchronize(F->stream));
+        if (herr) return fail(MI355_INVALID, "symbolic factor invalid: a descendant row is missing from its ancestor");
+    }
+    return MI355_OK;
+}
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];   // 0 gemm 1 potrf 2 asm
+    bool on = false;
+    hipStream_t st = nullptr;
+    void begin(int kind)
+    {
+        if (!on) return;
+        hipEvent_t x, y;
+        (void)hipEventCreate(&x); (void)hipEventCreate(&y);
+        (void)hipEventRecord(x, st);
+        ev[kind].push_back({x, y});
+    }
+    void end(int kind)
+    {
+        if (!on) return;
+        (void)hipEventRecord(ev[kind].back().second, st);
+    }
+    double collect(int kind)
+    {
+        double ms = 0;
+        for (auto &p : ev[kind]) {
+            float t = 0;
+            (void)hipEventSynchronize(p.second);
+            (void)hipEventElapsedTime(&t, p.first, p.second);
+            ms += t;
+            (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        }
+        ev[kind].clear();
+        return ms;
+    }
+};
+
+// run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
+int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm)
+{
+    const Symbolic &S = F->sym;
+    tm.begin(2);
+    HIP_TRY(hipMemsetAsync(F->Lx.p, 0, (size_t)S.xsize * sizeof(double), F->stream));
+    HIP_TRY(hipMemsetAsync(F->info.p, 0, (size_t)(S.nsuper + 2) * sizeof(int), F->stream));
+    if (ncols_asm > 0) {
+        const unsigned grid = (unsigned)((ncols_asm + 255) / 256);
+        hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm, F->Ap.p, F->Ai.p,
+                           F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
+                           F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta);
+        HIP_TRY(hipGetLastError());
+    }
+    tm.end(2);
+    for (const Step &st : D.sched.steps) {
+        if (st.count <= 0) continue;
+        if (st.kind == STEP_POTRF) {
+            if (st.count > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many POTRF tasks in one step");
+            tm.begin(1);
+            hipLaunchKernelGGL(k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                               D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p);
+            tm.end(1);
+            F->st_npotrf += 1;
+        } else {
+            if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
+                return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
+            tm.begin(0);
+            hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                               D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+            tm.end(0);
+            F->st_ngemm += 1;
+            F->st_tiles += (double)st.ntiles;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return MI355_OK;
+}
+
+int check_handle(mi355_factor_s *F)
+{
+    if (!F) return fail(MI355_INVALID, "null factor handle");
+    HIP_TRY(hipSetDevice(F->device));
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mi355_last_error(void) { return g_err.c_str(); }
+
+int mi355_probe(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    return usable;
+}
+
+int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Super,
+                        const int64_t *Lpi, const int64_t *Lpx, const int64_t *Ls,
+                        int64_t ssize, int64_t xsize, int device, mi355_factor **handle)
+{
+    g_err.clear();
+    if (!handle) return fail(MI355_INVALID, "null handle pointer");
+    *handle = nullptr;
+    if (xtype != MI355_REAL)
+        return fail(MI355_NOT_INSTALLED, "only real double factors are handled on the device so far");
+    if (n < 0 || nsuper < 0 || ssize < 0 || xsize < 0) return fail(MI355_INVALID, "negative size");
+    if (nsuper > 0 && (!Super || !Lpi || !Lpx || !Ls)) return fail(MI355_INVALID, "null symbolic array");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MI355_GPU_PROBLEM, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MI355_INVALID, "device index out of range");
+
+    mi355_factor_s *F = new (std::nothrow) mi355_factor_s;
+    if (!F) return fail(MI355_OUT_OF_MEMORY, "host out of memory");
+    struct Guard { mi355_factor_s *f; ~Guard() { if (f) mi355_factor_free(f); } } guard{F};
+    F->device = device;
+    F->xtype = xtype;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+
+    F->Super.assign(Super, Super + (nsuper > 0 ? nsuper + 1 : 0));
+    F->Lpi.assign(Lpi, Lpi + (nsuper > 0 ? nsuper + 1 : 0));
+    F->Lpx.assign(Lpx, Lpx + (nsuper > 0 ? nsuper + 1 : 0));
+    const int64_t nls = nsuper > 0 ? Lpi[nsuper] : 0;
+    if (nls < 0 || nls > ssize) return fail(MI355_INVALID, "Lpi[nsuper] exceeds ssize");
+    F->Ls.assign(Ls, Ls + nls);
+    F->sym.n = n; F->sym.nsuper = nsuper; F->sym.ssize = ssize; F->sym.xsize = xsize;
+    F->sym.Super = F->Super.data(); F->sym.Lpi = F->Lpi.data();
+    F->sym.Lpx = F->Lpx.data(); F->sym.Ls = F->Ls.data();
+    const std::string bad = validate_symbolic(F->sym);
+    if (!bad.empty()) return fail(MI355_INVALID, "invalid supernodal symbolic factor: " + bad);
+
+    build_schedule(F->sym, nsuper, 0, F->full.sched);
+
+    // device copies of the symbolic arrays (row indices narrowed to int32)
+    std::vector<int32_t> ls32((size_t)nls);
+    for (int64_t i = 0; i < nls; i++) ls32[i] = (int32_t)F->Ls[i];
+    HIP_TRY(F->dLs.upload(ls32.data(), ls32.size(), F->stream));
+    HIP_TRY(F->dSupermap.upload(F->full.sched.supermap.data(), F->full.sched.supermap.size(), F->stream));
+    HIP_TRY(F->dSuper.upload(F->Super.data(), F->Super.size(), F->stream));
+    HIP_TRY(F->dLpi.upload(F->Lpi.data(), F->Lpi.size(), F->stream));
+    HIP_TRY(F->dLpx.upload(F->Lpx.data(), F->Lpx.size(), F->stream));
+    HIP_TRY(F->Lx.alloc((size_t)xsize));
+    HIP_TRY(F->Dinv.alloc((size_t)F->full.sched.dinv_size));
+    HIP_TRY(F->info.alloc((size_t)nsuper + 2));
+    int rc = upload_schedule(F, F->full);
+    if (rc != MI355_OK) return rc;
+    guard.f = nullptr;
+    *handle = F;
+    return MI355_OK;
+}
+
+int mi355_factor_free(mi355_factor *F)
+{
+    if (!F) return MI355_OK;
+    (void)hipSetDevice(F->device);
+    if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
+    delete F;
+    return MI355_OK;
+}
+
+int mi355_factor_set_matrix(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
+                            const int64_t *Anz, const double *Ax)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const int64_t n = F->sym.n;
+    F->have_A = false;
+    if (n == 0) { F->have_A = true; return MI355_OK; }
+    if (!Ap || !Ai || !Ax) return fail(MI355_INVALID, "null matrix array");
+    // extent of Ai/Ax actually referenced
+    int64_t nzmax = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t p = Ap[k], pend = Anz ? p + Anz[k] : Ap[k + 1];
+        if (p < 0 || pend < p) return fail(MI355_INVALID, "matrix column pointers invalid");
+        nzmax = std::max(nzmax, pend);
+    }
+    if (!Anz) nzmax = std::max(nzmax, Ap[n]);
+    for (int64_t p = 0; p < nzmax; p++)
+        if (Ai[p] < 0 || Ai[p] >= n) return fail(MI355_INVALID, "matrix row index out of range");
+    HIP_TRY(F->Ap.upload(Ap, (size_t)n + 1, F->stream));
+    HIP_TRY(F->Ai.upload(Ai, (size_t)nzmax, F->stream));
+    HIP_TRY(F->Ax.upload(Ax, (size_t)nzmax, F->stream));
+    F->A_unpacked = (Anz != nullptr);
+    if (Anz) HIP_TRY(F->Anz.upload(Anz, (size_t)n, F->stream));
+    F->have_A = true;
+    return MI355_OK;
+}
+
+int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_not_posdef,
+                         int64_t *minor, int *status)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
+    const Symbolic &S = F->sym;
+    F->numeric_ok = false;
+    F->st_ngemm = F->st_npotrf = F->st_tiles = 0;
+    if (S.n == 0 || S.nsuper == 0) {
+        F->minor = S.n; F->numeric_ok = true;
+        if (minor) *minor = S.n;
+        if (status) *status = MI355_STATUS_OK;
+        return MI355_OK;
+    }
+    EventTimer tm;
+    tm.on = F->profile != 0;
+    tm.st = F->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, F->stream));
+
+    rc = run_schedule(F, F->full, S.n, beta_re, tm);
+    if (rc) return rc;
+    int *first = F->info.p + S.nsuper;
+    const int big = 0x7f7f7f7f;
+    HIP_TRY(hipMemsetAsync(first, 0x7f, sizeof(int), F->stream));
+    hipLaunchKernelGGL(k_first_info, dim3((unsigned)((S.nsuper + 255) / 256)), dim3(256), 0, F->stream,
+                       S.nsuper, F->info.p, first);
+    HIP_TRY(hipGetLastError());
+    int sf = big;
+    HIP_TRY(hipMemcpyAsync(&sf, first, sizeof(int), hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+
+    int st_out = MI355_STATUS_OK;
+    int64_t minor_out = S.n;
+    if (sf != big) {
+        // not positive definite: worker :1084-1146.  Supernode sf holds the first bad pivot.
+        int info = 0;
+        HIP_TRY(hipMemcpy(&info, F->info.p + sf, sizeof(int), hipMemcpyDeviceToHost));
+        st_out = MI355_STATUS_NOT_POSDEF;
+        minor_out = S.Super[sf] + info - 1;
+        const int64_t nscol2 = (info == 1 || quick_return_if_not_posdef) ? 0 : info - 1;
+        DeviceSchedule trunc;
+        build_schedule(S, sf, nscol2, trunc.sched);
+        rc = upload_schedule(F, trunc);
+        if (rc) return rc;
+        const int64_t ncols_asm = (nscol2 > 0) ? S.Super[sf + 1] : S.Super[sf];
+        rc = run_schedule(F, trunc, ncols_asm, beta_re, tm);
+        if (rc) return rc;
+        const int64_t nsrow = S.Lpi[sf + 1] - S.Lpi[sf];
+        const int64_t tail = S.Lpx[sf] + nsrow * nscol2;
+        if (tail < S.xsize)
+            HIP_TRY(hipMemsetAsync(F->Lx.p + tail, 0, (size_t)(S.xsize - tail) * sizeof(double), F->stream));
+        HIP_TRY(hipStreamSynchronize(F->stream));
+    }
+    HIP_TRY(hipEventRecord(e1, F->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    F->st_total = ms;
+    if (tm.on) { F->st_gemm = tm.collect(0); F->st_potrf = tm.collect(1); F->st_asm = tm.collect(2); }
+    F->minor = minor_out;
+    F->numeric_ok = (st_out == MI355_STATUS_OK);
+    if (minor) *minor = minor_out;
+    if (status) *status = st_out;
+    return MI355_OK;
+}
+
+int mi355_factor_get_Lx(mi355_factor *F, double *Lx)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!Lx) return fail(MI355_INVALID, "null Lx");
+    if (F->sym.xsize > 0) {
+        HIP_TRY(hipMemcpyAsync(Lx, F->Lx.p, (size_t)F->sym.xsize * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+        HIP_TRY(hipStreamSynchronize(F->stream));
+    }
+    return MI355_OK;
+}
+
+int mi355_super_numeric(mi355_factor *F, const int64_t *Ap, const int64_t *Ai, const int64_t *Anz,
+                        const double *Ax, double beta_re, int quick_return_if_not_posdef,
+                        double *Lx, int64_t *minor, int *status)
+{
+    int rc = mi355_factor_set_matrix(F, Ap, Ai, Anz, Ax);
+    if (rc) return rc;
+    rc = mi355_factor_numeric(F, beta_re, quick_return_if_not_posdef, minor, status);
+    if (rc) return rc;
+    return mi355_factor_get_Lx(F, Lx);
+}
+
+static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d)
+{
+    const Symbolic &S = F->sym;
+    if (nrhs < 0 || d < S.n) return fail(MI355_INVALID, "X and L dimensions must match");
+    if (S.n == 0 || nrhs == 0) return MI355_OK;
+    if (!F->numeric_ok) return fail(MI355_INVALID, "no positive-definite numeric factor is resident");
+    if (nrhs > 0x7fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
+    const std::vector<Step> &steps = F->full.sched.steps;
+    const PotrfTask *P = F->full.potrf.p;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, F->stream));
+    const int nr = (int)nrhs;
+    if (lower) {
+        for (size_t i = 0; i < steps.size(); i++) {
+            const Step &st = steps[i];
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            hipLaunchKernelGGL(k_solve_diag<false>, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                               P + st.first, F->Dinv.p, X, d, nr);
+            if (st.stiles > 0)
+                hipLaunchKernelGGL(k_solve_fwd_update, dim3((unsigned)st.stiles), dim3(SOLVE_ROWS), 0, F->stream,
+                                   P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        for (size_t i = steps.size(); i-- > 0;) {
+            const Step &st = steps[i];
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            if (st.stiles > 0)
+                hipLaunchKernelGGL(k_solve_bwd_update, dim3((unsigned)st.stiles), dim3(SOLVE_ROWS), 0, F->stream,
+                                   P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
+            hipLaunchKernelGGL(k_solve_diag<true>, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                               P + st.first, F->Dinv.p, X, d, nr);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, F->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    F->st_solve = ms;
+    return MI355_OK;
+}
+
+static int solve_host(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const int64_t n = F->sym.n;
+    if (nrhs < 0 || d < n) return fail(MI355_INVALID, "X and L dimensions must match");
+    if (n == 0 || nrhs == 0) return MI355_OK;
+    if (!X) return fail(MI355_INVALID, "null X");
+    DevBuf<double> dX;
+    HIP_TRY(dX.alloc((size_t)n * nrhs));
+    HIP_TRY(hipMemcpy2DAsync(dX.p, n * sizeof(double), X, d * sizeof(double), n * sizeof(double),
+                             (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
+    rc = solve_dev(F, lower, nrhs, dX.p, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(X, d * sizeof(double), dX.p, n * sizeof(double), n * sizeof(double),
+                             (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
+}
+
+int mi355_super_lsolve(mi355_factor *F, int64_t nrhs, double *X, int64_t d) { return solve_host(F, true, nrhs, X, d); }
+int mi355_super_ltsolve(mi355_factor *F, int64_t nrhs, double *X, int64_t d) { return solve_host(F, false, nrhs, X, d); }
+
+int mi355_super_lsolve_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    return solve_dev(F, true, nrhs, X, d);
+}
+
+int mi355_super_ltsolve_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    return solve_dev(F, false, nrhs, X, d);
+}
+
+double *mi355_factor_device_Lx(mi355_factor *F) { return F ? F->Lx.p : nullptr; }
+
+int mi355_factor_set_profile(mi355_factor *F, int profile)
+{
+    if (!F) return fail(MI355_INVALID, "null factor handle");
+    F->profile = profile;
+    return MI355_OK;
+}
+
+int mi355_factor_get_stats(mi355_factor *F, double *out)
+{
+    if (!F || !out) return fail(MI355_INVALID, "null argument");
+    const Schedule &S = F->full.sched;
+    out[0] = F->st_total; out[1] = F->st_gemm; out[2] = F->st_ngemm; out[3] = F->st_potrf;
+    out[4] = F->st_npotrf; out[5] = F->st_asm; out[6] = S.flops_update; out[7] = S.flops_panel;
+    out[8] = S.bytes_assembly; out[9] = (double)S.pairs.size(); out[10] = (double)S.nlevels;
+    out[11] = (double)S.relmap_size; out[12] = (double)S.dinv_size; out[13] = F->st_solve;
+    out[14] = F->st_tiles; out[15] = 0;
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// kernels.hip.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the supernodal
+// numeric engine.  Real double precision (E = 1).  Included by engine.hip only.
+//
+// Kernel            replaces (reference)                                     bound
+// k_assemble        A-scatter + beta, worker :438-520                        HBM
+// k_relmap          Map/RelativeMap, worker :392-399,:896-903 and            HBM (once per symbolic)
+//                   kernelCreateMap/kernelCreateRelativeMap (CHOLMOD/GPU/cholmod_gpu_kernels.cu:21-41)
+// k_gemm64          dsyrk+dgemm+assembly (worker :769-930; cublasDsyrk/Dgemm +  FP64 MFMA
+//                   kernelAddUpdate, CHOLMOD/GPU/t_cholmod_gpu.c:502-582),
+//                   trailing updates and TRSM-by-inverse inside dpotrf/dtrsm
+//                   (worker :1023,:1175; t_cholmod_gpu.c:784-1135,1151-1393)
+// k_potrf64         dpotrf of one <=64 diagonal block + its inverse            latency
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "schedule.hpp"
+
+namespace mi355 {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// hardware FP64 atomic add (global_atomic_add_f64); no CAS loop
+__device__ __forceinline__ void atomic_add_f64(double *p, double v)
+{
+    unsafeAtomicAdd(p, v);
+}
+
+// position of `key` in the sorted int32 list a[0..len); -1 if absent
+__device__ __forceinline__ int find_row(const int32_t *__restrict__ a, int len, int key)
+{
+    int lo = 0, hi = len - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        int v = a[mid];
+        if (v == key) return mid;
+        if (v < key) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+//------------------------------------------------------------------------------
+// k_assemble: Lx <- A (lower part) + beta*I, one thread per column
+//------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(
+    int64_t ncols, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+    const int64_t *__restrict__ Anz, const double *__restrict__ Ax,
+    const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
+    const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx,
+    const int32_t *__restrict__ Ls, double *__restrict__ Lx, double beta)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int s = supermap[k];
+    const int64_t k1 = Super[s], psi = Lpi[s], psx = Lpx[s];
+    const int nsrow = (int)(Lpi[s + 1] - psi);
+    const int64_t colbase = psx + (k - k1) * (int64_t)nsrow;
+    int64_t p = Ap[k];
+    const int64_t pend = Anz ? p + Anz[k] : Ap[k + 1];
+    for (; p < pend; p++) {
+        const int64_t i = Ai[p];
+        if (i >= k) {
+            const int imap = find_row(Ls + psi, nsrow, (int)i);
+            if (imap >= 0) Lx[colbase + imap] = Ax[p];
+        }
+    }
+    if (beta != 0.0) Lx[colbase + (k - k1)] += beta;
+}
+
+//------------------------------------------------------------------------------
+// k_relmap: relmap[rm_off + i] = position of Ls[ls_src + i] in the row list of s
+//------------------------------------------------------------------------------
+struct RelmapPair { int64_t ls_src, ls_dst, rm_off; int32_t nsrow, pad; };
+
+__global__ __launch_bounds__(256) void k_relmap(
+    int64_t total, int64_t npairs, const RelmapPair *__restrict__ pairs,
+    const int32_t *__restrict__ Ls, int32_t *__restrict__ relmap, int *__restrict__ err)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int64_t lo = 0, hi = npairs - 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) >> 1;
+        if (pairs[mid].rm_off <= e) lo = mid; else hi = mid - 1;
+    }
+    const RelmapPair pr = pairs[lo];
+    const int row = Ls[pr.ls_src + (e - pr.rm_off)];
+    const int pos = find_row(Ls + pr.ls_dst, pr.nsrow, row);
+    if (pos < 0) { *err = 1; relmap[e] = 0; } else relmap[e] = pos;
+}
+
+//------------------------------------------------------------------------------
+// tile index -> (tm, tn) inside one task
+//------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_coords(int64_t t, int MT, int NT, int mode, int &tm, int &tn)
+{
+    if (mode == GEMM_OVERWRITE || MT < NT) { tm = (int)(t / NT); tn = (int)(t % NT); return; }
+    const int64_t tri = (int64_t)NT * (NT + 1) / 2;
+    if (t < tri) {
+        int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(r + 1) * (r + 2) / 2 <= t) r++;
+        while ((int64_t)r * (r + 1) / 2 > t) r--;
+        tm = r; tn = (int)(t - (int64_t)r * (r + 1) / 2);
+    } else {
+        const int64_t q = t - tri;
+        tm = NT + (int)(q / NT); tn = (int)(q % NT);
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_gemm64: batched C = A * B^T on v_mfma_f64_16x16x4_f64, 64x64 tile per workgroup
+// (4 waves as 2x2, each wave 32x32 = 2x2 MFMA blocks), K staged through LDS in steps
+// of 16, epilogue by mode (atomic scatter-subtract / direct subtract / overwrite).
+//
+// MFMA operand roles are swapped on purpose: the B-matrix rows feed the MFMA "A"
+// operand and the A-matrix rows the MFMA "B" operand, so that in the result the LANE
+// index (lane & 15) runs along m -- the direction that is contiguous in Lx -- and each
+// store/atomic wave-instruction touches 4 runs of 16 consecutive doubles.
+//------------------------------------------------------------------------------
+constexpr int G64_KS = 16;          // K per LDS stage
+constexpr int G64_LD = 80;          // padded row stride (doubles): 640 B, lanes 16..31 land on banks 32..63
+
+__global__ __launch_bounds__(256) void k_gemm64(
+    const GemmTask *__restrict__ tasks, int ntasks, double *__restrict__ Lx,
+    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
+{
+    __shared__ double As[G64_KS][G64_LD];
+    __shared__ double Bs[G64_KS][G64_LD];
+    __shared__ int rmM[TILE], rmN[TILE];
+
+    const int tid = threadIdx.x;
+    const int64_t bid = blockIdx.x;
+    int lo = 0, hi = ntasks - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const GemmTask t = tasks[lo];
+    const int M = t.M, N = t.N, K = t.K, mode = t.mode;
+    const int MT = (M + TILE - 1) / TILE, NT = (N + TILE - 1) / TILE;
+    int tm, tn;
+    tile_coords(bid - t.tile0, MT, NT, mode, tm, tn);
+    if (tm >= MT || tn >= NT) return;           // host guarantees this never happens
+    const int m0 = tm * TILE, n0 = tn * TILE;
+
+    const double *__restrict__ A = Lx + t.a_off;
+    const double *__restrict__ B = (mode == GEMM_OVERWRITE ? Dinv : Lx) + t.b_off;
+    const int64_t lda = t.lda, ldb = t.ldb;
+
+    if (mode == GEMM_SCATTER_SUB) {
+        if (tid < TILE) rmM[tid] = (m0 + tid < M) ? relmap[t.rm_off + m0 + tid] : 0;
+        else if (tid < 2 * TILE) { int j = tid - TILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    v4d acc[2][2];                               // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int lrow = tid & 63, lk = tid >> 6;
+    const bool arow_ok = (m0 + lrow) < M, brow_ok = (n0 + lrow) < N;
+    const double *Ap = A + (m0 + lrow);
+    const double *Bp = B + (n0 + lrow);
+
+    for (int k0 = 0; k0 < K; k0 += G64_KS) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lk + 4 * q, kk = k0 + k;
+            const bool kok = kk < K;
+            As[k][lrow] = (arow_ok && kok) ? Ap[(int64_t)kk * lda] : 0.0;
+            Bs[k][lrow] = (brow_ok && kok) ? Bp[(int64_t)kk * ldb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = ks * 4 + l4;
+            const double a0 = As[kk][wm * 32 + l15];
+            const double a1 = As[kk][wm * 32 + 16 + l15];
+            const double b0 = Bs[kk][wn * 32 + l15];
+            const double b1 = Bs[kk][wn * 32 + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  D row = (lane>>4) + 4*r  <-> n ; D col = lane & 15 <-> m
+    const int64_t ldc = t.ldc;
+    double *__restrict__ C = Lx + t.c_off;
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+            const int ml = wm * 32 + mi * 16 + l15;
+            const int m = m0 + ml;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nl = wn * 32 + ni * 16 + l4 + 4 * r;
+                const int n = n0 + nl;
+                if (m < M && n < N) {
+                    const double v = acc[ni][mi][r];
+                    if (mode == GEMM_SCATTER_SUB) {
+                        if (m >= n) atomic_add_f64(C + rmM[ml] + (int64_t)rmN[nl] * ldc, -v);
+                    } else if (mode == GEMM_DIRECT_SUB) {
+                        if (m >= n) C[m + (int64_t)n * ldc] -= v;
+                    } else {
+                        C[m + (int64_t)n * ldc] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_potrf64: lower Cholesky of one nb x nb (nb <= 64) diagonal block, in LDS, plus
+// its inverse (used as the TRSM operand and by the solves).  One workgroup per task.
+// info[s] receives the 1-based column (inside s) of the first pivot that is <= 0 or
+// NaN -- LAPACK dpotrf's INFO, worker :1023-1027,:1084-1095.
+//------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potrf64(
+    const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
+    double *__restrict__ Dinv, int *__restrict__ info)
+{
+    __shared__ double Ls[NB][NB + 1];
+    const PotrfTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nb = t.nb;
+    const int64_t lda = t.lda;
+    double *__restrict__ A = Lx + t.a_off;
+
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int i = idx & (NB - 1), j = idx >> 6;
+        double v = (i == j) ? 1.0 : 0.0;                     // identity padding
+        if (i < nb && j < nb) v = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
+        Ls[i][j] = v;
+    }
+    __syncthreads();
+
+    bool failed = false;
+    for (int j = 0; j < nb; j++) {
+        const double d = Ls[j][j];
+        if (!(d > 0.0) && !failed) {
+            failed = true;
+            if (tid == 0 && info[t.s] == 0) info[t.s] = t.col0 + j + 1;
+        }
+        const double ljj = sqrt(d);
+        __syncthreads();
+        if (tid == 0) Ls[j][j] = ljj;
+        for (int i = j + 1 + tid; i < nb; i += 256) Ls[i][j] /= ljj;
+        __syncthreads();
+        const int i = j + 1 + (tid & 63);
+        if (i < nb) {
+            const double lij = Ls[i][j];
+            for (int k = j + 1 + (tid >> 6); k <= i; k += 4) Ls[i][k] -= lij * Ls[k][j];
+        }
+        __syncthreads();
+    }
+
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int i = idx & (NB - 1), j = idx >> 6;
+        if (i < nb && j < nb && i >= j) A[i + (int64_t)j * lda] = Ls[i][j];
+    }
+
+    // inverse of the (identity-padded) 64x64 lower-triangular block: lane c of wave 0
+    // solves L x = e_c by a fully unrolled column sweep held in registers
+    double x[NB];
+    if (tid < NB) {
+        const int c = tid;
+#pragma unroll
+        for (int i = 0; i < NB; i++) x[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const double xk = x[k] / Ls[k][k];
+            x[k] = xk;
+#pragma unroll
+            for (int i = k + 1; i < NB; i++) x[i] -= Ls[i][k] * xk;
+        }
+    }
+    __syncthreads();                                          // all reads of L done
+    if (tid < NB) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) Ls[i][tid] = x[i];       // Ls := inv(L)
+    }
+    __syncthreads();
+    if (t.dinv_off >= 0) {
+        double *__restrict__ D = Dinv + t.dinv_off;
+        for (int idx = tid; idx < nb * nb; idx += 256) {
+            const int i = idx % nb, j = idx / nb;
+            D[idx] = (i >= j) ? Ls[i][j] : 0.0;               // column-major, ld = nb
+        }
+    }
+}
+
+}  // namespace mi355

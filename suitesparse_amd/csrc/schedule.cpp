@@ -1,0 +1,252 @@
+// schedule.cpp -- see schedule.hpp.  Pure host C++.
+#include "schedule.hpp"
+#include <algorithm>
+#include <cstdio>
+
+namespace mi355 {
+
+int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile)
+{
+    if (M <= 0 || N <= 0) return 0;
+    int64_t MT = (M + tile - 1) / tile, NT = (N + tile - 1) / tile;
+    if (mode == GEMM_OVERWRITE) return MT * NT;
+    // lower trapezoid (M >= N): tile row tm holds min(tm+1, NT) tiles
+    if (MT < NT) return MT * NT;    // never for our tasks; kept safe
+    return NT * (NT + 1) / 2 + (MT - NT) * NT;
+}
+
+std::string validate_symbolic(const Symbolic &S)
+{
+    char buf[256];
+    if (S.n < 0 || S.nsuper < 0) return "negative dimension";
+    if (S.n == 0 || S.nsuper == 0) return (S.n == 0 && S.nsuper == 0) ? "" : "n/nsuper mismatch";
+    if (!S.Super || !S.Lpi || !S.Lpx || !S.Ls) return "null symbolic array";
+    if (S.n >= (int64_t(1) << 31) - 1) return "n too large for 32-bit row indices";
+    if (S.Super[0] != 0 || S.Super[S.nsuper] != S.n) return "Super does not span 0..n";
+    if (S.Lpi[0] != 0 || S.Lpx[0] != 0) return "Lpi[0]/Lpx[0] must be 0";
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        int64_t nscol = S.Super[s + 1] - S.Super[s];
+        int64_t nsrow = S.Lpi[s + 1] - S.Lpi[s];
+        if (nscol <= 0 || nsrow < nscol) {
+            snprintf(buf, sizeof buf, "supernode %lld: nscol %lld nsrow %lld", (long long)s,
+                     (long long)nscol, (long long)nsrow);
+            return buf;
+        }
+        if (S.Lpx[s + 1] - S.Lpx[s] != nscol * nsrow) {
+            snprintf(buf, sizeof buf, "supernode %lld: Lpx does not match nsrow*nscol", (long long)s);
+            return buf;
+        }
+        const int64_t *rows = S.Ls + S.Lpi[s];
+        for (int64_t k = 0; k < nsrow; k++) {
+            int64_t want_min = (k < nscol) ? S.Super[s] + k : rows[k - 1] + 1;
+            if ((k < nscol && rows[k] != want_min) || rows[k] < want_min || rows[k] >= S.n) {
+                snprintf(buf, sizeof buf, "supernode %lld: row list invalid at %lld", (long long)s,
+                         (long long)k);
+                return buf;
+            }
+        }
+    }
+    if (S.Lpi[S.nsuper] > S.ssize || S.Lpx[S.nsuper] > S.xsize) return "ssize/xsize too small";
+    return "";
+}
+
+namespace {
+
+struct LevelSteps {
+    // per iteration it: tasks of all supernodes of this level
+    std::vector<std::vector<PotrfTask>> potrf;
+    std::vector<std::vector<GemmTask>> trsm, trail;
+    std::vector<GemmTask> updates;
+    void ensure(size_t it)
+    {
+        if (potrf.size() <= it) { potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); }
+    }
+};
+
+GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int64_t ldb, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, int32_t mode)
+{
+    GemmTask t;
+    t.a_off = a; t.b_off = b; t.c_off = c; t.rm_off = rm;
+    t.lda = (int32_t)lda; t.ldb = (int32_t)ldb; t.ldc = (int32_t)ldc;
+    t.M = (int32_t)M; t.N = (int32_t)N; t.K = (int32_t)K;
+    t.mode = mode; t.big = 0; t.tile0 = 0;
+    return t;
+}
+
+// append one GEMM step; assigns tile0 prefix sums; splits nothing
+void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level)
+{
+    if (tasks.empty()) return;
+    Step st;
+    st.kind = STEP_GEMM; st.level = level; st.big = 0; st.pad = 0;
+    st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
+    for (auto &t : tasks) {
+        int64_t nt = gemm_tiles(t.M, t.N, t.mode, TILE);
+        if (nt == 0) continue;
+        t.tile0 = st.ntiles;
+        st.ntiles += nt;
+        out.gemm.push_back(t);
+        st.count++;
+    }
+    if (st.count > 0) out.steps.push_back(st);
+}
+
+}  // namespace
+
+void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out)
+{
+    out = Schedule();
+    const int64_t ns = S.nsuper;
+    out.s_limit = s_limit;
+    out.nscol2_limit = nscol2_limit;
+    if (ns == 0) return;
+    const bool truncated = (s_limit < ns);
+    // supernodes processed at all: s < s_end
+    const int64_t s_end = truncated ? (nscol2_limit > 0 ? s_limit + 1 : s_limit) : ns;
+
+    // column -> supernode (cholmod_super_numeric.c:276-285)
+    out.supermap.resize(S.n);
+    for (int64_t s = 0; s < ns; s++)
+        for (int64_t k = S.Super[s]; k < S.Super[s + 1]; k++) out.supermap[k] = (int32_t)s;
+
+    // supernodal etree: parent = SuperMap[Ls[psi+nscol]] (worker :1226)
+    out.parent.assign(ns, -1);
+    out.level.assign(ns, 0);
+    for (int64_t s = 0; s < ns; s++) {
+        int64_t nscol = S.Super[s + 1] - S.Super[s];
+        int64_t nsrow = S.Lpi[s + 1] - S.Lpi[s];
+        out.max_nscol = std::max(out.max_nscol, nscol);
+        out.max_nsrow = std::max(out.max_nsrow, nsrow);
+        if (nsrow > nscol) out.parent[s] = out.supermap[S.Ls[S.Lpi[s] + nscol]];
+    }
+    for (int64_t s = 0; s < ns; s++) {
+        int32_t p = out.parent[s];
+        if (p >= 0) out.level[p] = std::max(out.level[p], out.level[s] + 1);
+    }
+    int32_t nlev = 0;
+    for (int64_t s = 0; s < s_end; s++) nlev = std::max(nlev, out.level[s] + 1);
+    out.nlevels = nlev;
+
+    std::vector<LevelSteps> L(nlev);
+
+    for (int64_t s = 0; s < s_end; s++) {
+        const int lev = out.level[s];
+        const int64_t nscol = S.Super[s + 1] - S.Super[s];
+        const int64_t nsrow = S.Lpi[s + 1] - S.Lpi[s];
+        const int64_t psx = S.Lpx[s];
+        const int64_t ncol_eff = (truncated && s == s_limit) ? nscol2_limit : nscol;
+
+        // ---- panel: blocked partial Cholesky of the nsrow x ncol_eff panel (a3.9 + a3.10)
+        size_t it = 0;
+        for (int64_t J = 0; J < ncol_eff; J += OB) {
+            const int64_t Jend = std::min<int64_t>(J + OB, ncol_eff);
+            for (int64_t j = J; j < Jend; j += NB, it++) {
+                const int64_t nb = std::min<int64_t>(NB, Jend - j);
+                const int64_t below = nsrow - (j + nb);
+                L[lev].ensure(it);
+                PotrfTask pt;
+                pt.a_off = psx + j + j * nsrow;
+                pt.dinv_off = (below > 0) ? 0 : -1;     // slot assigned when the step is flushed
+                pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
+                pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
+                pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
+                L[lev].potrf[it].push_back(pt);
+                out.flops_panel += (double)nb * nb * nb / 3.0;
+                if (below > 0) {
+                    // X = B * inv(L11)^H  (trsm "R","L","C","N", worker :1175)
+                    GemmTask t = make_gemm(psx + (j + nb) + j * nsrow, /*b: slot, set later*/ 0,
+                                           psx + (j + nb) + j * nsrow, -1, nsrow, nb, nsrow,
+                                           below, nb, nb, GEMM_OVERWRITE);
+                    L[lev].trsm[it].push_back(t);
+                    out.flops_panel += (double)below * nb * nb;
+                    const int64_t ninner = Jend - (j + nb);
+                    if (ninner > 0) {
+                        L[lev].trail[it].push_back(make_gemm(
+                            psx + (j + nb) + j * nsrow, psx + (j + nb) + j * nsrow,
+                            psx + (j + nb) + (j + nb) * nsrow, -1, nsrow, nsrow, nsrow,
+                            below, ninner, nb, GEMM_DIRECT_SUB));
+                        out.flops_panel += 2.0 * below * ninner * nb;
+                    }
+                    if (j + nb == Jend && Jend < ncol_eff) {
+                        const int64_t K = Jend - J;
+                        L[lev].trail[it].push_back(make_gemm(
+                            psx + Jend + J * nsrow, psx + Jend + J * nsrow,
+                            psx + Jend + Jend * nsrow, -1, nsrow, nsrow, nsrow,
+                            nsrow - Jend, ncol_eff - Jend, K, GEMM_DIRECT_SUB));
+                        out.flops_panel += 2.0 * (double)(nsrow - Jend) * (ncol_eff - Jend) * K;
+                    }
+                }
+            }
+        }
+
+        // ---- updates pushed by s into its ancestors (a3.4-a3.8), right-looking
+        if (truncated && s >= s_limit) continue;     // the repeated supernode pushes nothing
+        const int64_t pdi = S.Lpi[s], pdend = S.Lpi[s + 1];
+        int64_t p = pdi + nscol;
+        while (p < pdend) {
+            const int32_t anc = out.supermap[S.Ls[p]];
+            int64_t q = p;
+            while (q < pdend && out.supermap[S.Ls[q]] == anc) q++;
+            const int64_t ndrow1 = q - p, ndrow2 = pdend - p;
+            const bool keep = !truncated || anc < s_limit || (anc == s_limit && nscol2_limit > 0);
+            if (keep) {
+                UpdatePair up;
+                up.d = (int32_t)s; up.s = anc;
+                up.ls_src = p; up.ls_dst = S.Lpi[anc];
+                up.ndrow1 = (int32_t)ndrow1; up.ndrow2 = (int32_t)ndrow2;
+                up.nsrow = (int32_t)(S.Lpi[anc + 1] - S.Lpi[anc]);
+                up.rm_off = out.relmap_size;
+                out.relmap_size += ndrow2;
+                out.pairs.push_back(up);
+                const int64_t a = psx + (p - pdi);
+                L[lev].updates.push_back(make_gemm(a, a, S.Lpx[anc], up.rm_off, nsrow, nsrow, up.nsrow,
+                                                   ndrow2, ndrow1, nscol, GEMM_SCATTER_SUB));
+                out.flops_update += (double)ndrow1 * ndrow1 * nscol
+                                  + 2.0 * (double)(ndrow2 - ndrow1) * ndrow1 * nscol;
+                out.bytes_assembly += (double)ndrow1 * ndrow2 * 8.0;
+            }
+            p = q;
+        }
+    }
+
+    // ---- flatten into launch order
+    for (int lev = 0; lev < nlev; lev++) {
+        LevelSteps &ls = L[lev];
+        for (size_t it = 0; it < ls.potrf.size(); it++) {
+            // assign Dinv slots for this step; the trsm task i pairs with the i-th potrf task
+            // that has rows below it (same push order)
+            // Every block keeps its inverse for the whole life of the factor (the solves
+            // reuse it): slots are global, sum nb^2 <= 64*n entries.
+            size_t ti = 0;
+            for (auto &pt : ls.potrf[it]) {
+                const bool has_below = (pt.dinv_off >= 0);
+                pt.dinv_off = out.dinv_size;
+                if (has_below) {
+                    ls.trsm[it][ti].b_off = pt.dinv_off;
+                    ti++;
+                }
+                out.dinv_size += (int64_t)pt.nb * pt.nb;
+            }
+            int64_t stiles = 0;
+            for (auto &pt : ls.potrf[it]) {
+                const int64_t below = (int64_t)pt.lda - (pt.col0 + pt.nb);
+                pt.stile0 = stiles;
+                stiles += (below + SOLVE_ROWS - 1) / SOLVE_ROWS;
+            }
+            Step st;
+            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.pad = 0;
+            st.first = (int64_t)out.potrf.size();
+            st.count = (int64_t)ls.potrf[it].size();
+            st.ntiles = st.count;
+            st.stiles = stiles;
+            out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
+            if (st.count > 0) out.steps.push_back(st);
+            flush_gemm(out, ls.trsm[it], lev);
+            flush_gemm(out, ls.trail[it], lev);
+        }
+        flush_gemm(out, ls.updates, lev);
+    }
+}
+
+}  // namespace mi355

@@ -1,0 +1,121 @@
+// schedule.hpp -- host-side (pure C++, no HIP) schedule builder for the MI355X
+// supernodal numeric engine.
+//
+// The reference walks linked lists Head/Next/Lpos while it factorizes
+// (CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:537-551,585-698,950-967,
+// 1222-1235).  That walk depends only on the symbolic structure (Super/Lpi/Ls), so
+// here it is replayed ONCE per symbolic factor into flat, level-ordered task lists
+// that the device consumes with a handful of batched launches per etree level:
+//
+//   level l:  [panel steps it = 0,1,..]  POTRF(diag 64-block) -> GEMM(trsm via
+//             inverse) -> GEMM(trailing update)          (all supernodes of level l)
+//             [update step]  GEMM(scatter) for every (d,s) pair with level(d) = l
+//
+// Descendant d updates ancestor s  <=>  s is a proper ancestor of d in the
+// supernodal etree, hence level(s) > level(d): every panel of level l is complete
+// (all its updates applied) when level l starts.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace mi355 {
+
+constexpr int NB = 64;        // diagonal-block / panel width of the device POTRF
+constexpr int OB = 256;       // outer block (trailing updates with K = OB)
+constexpr int TILE = 64;      // GEMM output tile (TILE x TILE per workgroup), small-tile kernel
+constexpr int BTILE = 128;    // big-tile kernel
+constexpr int SOLVE_ROWS = 256;  // rows of L per workgroup in the solve update kernels
+
+enum GemmMode : int32_t {
+    GEMM_SCATTER_SUB = 0,     // Lx[c_off + rm[i] + rm[j]*ldc] -= C(i,j), i>=j, atomic   (a3.5-a3.8)
+    GEMM_DIRECT_SUB  = 1,     // Lx[c_off + i + j*ldc]         -= C(i,j), i>=j           (inside a3.9/a3.10)
+    GEMM_OVERWRITE   = 2      // Lx[c_off + i + j*ldc]          = C(i,j)  (B from the Dinv workspace; TRSM a3.10)
+};
+
+// C (M x N) = A (M x K) * B (N x K)^H ; A, B column-major with leading dims lda, ldb.
+struct GemmTask {
+    int64_t a_off;      // entry offset of A(0,0) in Lx
+    int64_t b_off;      // entry offset of B(0,0) in Lx (or in the Dinv workspace, GEMM_OVERWRITE)
+    int64_t c_off;      // entry offset of the target origin in Lx
+    int64_t rm_off;     // offset of this pair's relative map (GEMM_SCATTER_SUB), else -1
+    int32_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t mode;
+    int32_t big;        // 1: tiles counted with BTILE (big-tile kernel), 0: TILE
+    int64_t tile0;      // first tile of this task inside its launch
+};
+
+struct PotrfTask {
+    int64_t a_off;      // entry offset of the diagonal block in Lx
+    int64_t dinv_off;   // entry offset of the nb x nb inverse (column-major, ld nb) in Dinv
+    int64_t ls_off;     // Lpi[s]: row list of the supernode (solves)
+    int64_t stile0;     // first solve row-tile of this block inside its step (solves)
+    int32_t lda;        // = nsrow
+    int32_t nb;         // block size (<= NB)
+    int32_t s;          // supernode
+    int32_t col0;       // first column of the block inside s (info = col0 + j + 1)
+    int32_t k1;         // Super[s]
+    int32_t nscol;      // columns of s
+};
+
+// one (descendant d -> ancestor s) update, the unit of a3.4 in SURVEY.md section 8
+struct UpdatePair {
+    int32_t d, s;
+    int64_t ls_src;     // index into Ls of the first row of d that lies in s (pdi1)
+    int64_t ls_dst;     // Lpi[s]
+    int32_t ndrow1, ndrow2, nsrow;
+    int64_t rm_off;     // offset of its relative map (ndrow2 entries)
+};
+
+enum StepKind : int32_t { STEP_POTRF = 0, STEP_GEMM = 1 };
+struct Step {
+    int32_t kind;
+    int32_t level;
+    int32_t big;        // STEP_GEMM: tasks of this step use the big-tile kernel
+    int32_t pad;
+    int64_t first;      // first task (index into potrf[] or gemm[])
+    int64_t count;      // number of tasks
+    int64_t ntiles;     // STEP_GEMM: total tiles (= grid size); STEP_POTRF: = count
+    int64_t stiles;     // STEP_POTRF: row tiles (SOLVE_ROWS rows each) below the blocks, for the solves
+};
+
+struct Symbolic {
+    int64_t n = 0, nsuper = 0, ssize = 0, xsize = 0;
+    const int64_t *Super = nullptr, *Lpi = nullptr, *Lpx = nullptr, *Ls = nullptr;
+};
+
+struct Schedule {
+    std::vector<int32_t> supermap;      // column -> supernode
+    std::vector<int32_t> parent;        // supernodal etree (-1 = root)
+    std::vector<int32_t> level;         // height above the leaves
+    int32_t nlevels = 0;
+    std::vector<PotrfTask> potrf;
+    std::vector<GemmTask> gemm;
+    std::vector<UpdatePair> pairs;
+    std::vector<Step> steps;
+    int64_t relmap_size = 0;            // total relative-map entries (sum of ndrow2 over pairs)
+    int64_t dinv_size = 0;              // total entries of the block inverses (sum nb^2)
+    // truncation (not-positive-definite repeat, worker :1084-1146); s_limit == nsuper: none
+    int64_t s_limit = 0;
+    int64_t nscol2_limit = 0;
+    // statistics
+    double flops_update = 0, flops_panel = 0;
+    double bytes_assembly = 0;          // sum over pairs of ndrow1*ndrow2*8
+    int64_t max_nscol = 0, max_nsrow = 0;
+};
+
+// Validates the symbolic factor (monotone pointers, sorted in-range row lists, the
+// leading nscol rows of each supernode are its own columns, cholmod_super_symbolic.c:
+// 779-782).  Returns "" if fine, else a message.
+std::string validate_symbolic(const Symbolic &S);
+
+// Full schedule: s_limit = nsuper.  Truncated schedule for the not-posdef repeat:
+// supernodes < s_limit are processed completely, supernode s_limit only in its first
+// nscol2_limit columns (0: not at all), later supernodes not at all.
+void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out);
+
+// number of TILE-tiles of one task
+int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile);
+
+}  // namespace mi355

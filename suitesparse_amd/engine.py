@@ -1,0 +1,198 @@
+"""ctypes binding of the C ABI in include/mi355_cholmod.h (libmi355_cholmod.so).
+
+The names mirror the reference's Supernodal module so that tests read like the
+reference's own (CHOLMOD/Tcov/t_raw_factor.c:186-280):
+
+    L = SupernodalFactor(sym)            # a supernodal symbolic cholmod_factor
+    status = L.super_numeric(S, beta)    # cholmod_super_numeric (cholmod_super_numeric.c:100)
+    L.super_lsolve(X); L.super_ltsolve(X)   # cholmod_super_lsolve / _ltsolve (cholmod_super_solve.c:52,153)
+
+There is no CPU path: if the shared library or a gfx950 device is missing, every
+call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_cholmod.so")
+
+CHOLMOD_OK = 0
+CHOLMOD_NOT_POSDEF = 1
+CHOLMOD_INVALID = -4
+CHOLMOD_GPU_PROBLEM = -5
+CHOLMOD_NOT_INSTALLED = -1
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+EXPORTS = [
+    "mi355_probe", "mi355_last_error", "mi355_factor_create", "mi355_factor_free",
+    "mi355_factor_set_matrix", "mi355_factor_numeric", "mi355_factor_get_Lx",
+    "mi355_super_numeric", "mi355_super_lsolve", "mi355_super_ltsolve",
+    "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
+    "mi355_factor_set_profile", "mi355_factor_get_stats",
+]
+
+_LIB = None
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mi355 error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libmi355_cholmod.so (fails loudly if it was not built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mi355Error(CHOLMOD_NOT_INSTALLED,
+                             f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.mi355_probe.restype = C.c_int
+        L.mi355_last_error.restype = C.c_char_p
+        L.mi355_factor_create.argtypes = [C.c_int, C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p,
+                                          C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi355_factor_free.argtypes = [C.c_void_p]
+        L.mi355_factor_set_matrix.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p]
+        L.mi355_factor_numeric.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int)]
+        L.mi355_factor_get_Lx.argtypes = [C.c_void_p, _f64p]
+        L.mi355_super_numeric.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, C.c_double, C.c_int,
+                                          _f64p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        for f in (L.mi355_super_lsolve, L.mi355_super_ltsolve):
+            f.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int64]
+        for f in (L.mi355_super_lsolve_dev, L.mi355_super_ltsolve_dev):
+            f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_factor_device_Lx.argtypes = [C.c_void_p]
+        L.mi355_factor_device_Lx.restype = C.c_void_p
+        L.mi355_factor_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_factor_get_stats.argtypes = [C.c_void_p, _f64p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise Mi355Error(rc, lib().mi355_last_error().decode(errors="replace"))
+
+
+def probe():
+    return lib().mi355_probe()
+
+
+STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
+             "flops_update", "flops_panel", "bytes_assembly", "npairs", "nlevels", "relmap_entries",
+             "dinv_entries", "solve_ms", "gemm_tiles", "reserved"]
+
+
+class SupernodalFactor:
+    """Device-resident supernodal factor (cholmod_factor with is_super, CHOLMOD/Include/cholmod.h:1584-1651)."""
+
+    def __init__(self, sym, device=0, xtype=1):
+        self.n = int(sym["n"])
+        self.nsuper = int(sym["nsuper"])
+        self.xsize = int(sym["xsize"])
+        self.ssize = int(sym.get("ssize", len(sym["Ls"])))
+        self.minor = self.n
+        self.status = CHOLMOD_OK
+        self.xtype = xtype
+        self._h = C.c_void_p()
+        Ls = np.ascontiguousarray(sym["Ls"], dtype=np.int64)
+        if Ls.size == 0:
+            Ls = np.zeros(1, dtype=np.int64)
+
+        def arr(a):
+            a = np.ascontiguousarray(a, dtype=np.int64)
+            return a if a.size else np.zeros(1, dtype=np.int64)
+        rc = lib().mi355_factor_create(xtype, self.n, self.nsuper, arr(sym["Super"]), arr(sym["Lpi"]),
+                                       arr(sym["Lpx"]), Ls, self.ssize, self.xsize, int(device),
+                                       C.byref(self._h))
+        _check(rc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mi355_factor_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- numeric ----
+    def set_matrix(self, Sp, Si, Sx, Snz=None):
+        Sp = np.ascontiguousarray(Sp, dtype=np.int64)
+        Si = np.ascontiguousarray(Si, dtype=np.int64)
+        Sx = np.ascontiguousarray(Sx, dtype=np.float64)
+        if Si.size == 0:
+            Si = np.zeros(1, dtype=np.int64)
+            Sx = np.zeros(1)
+        nz = None
+        if Snz is not None:
+            self._nz = np.ascontiguousarray(Snz, dtype=np.int64)
+            nz = self._nz.ctypes.data_as(C.c_void_p)
+        _check(lib().mi355_factor_set_matrix(self._h, Sp, Si, nz, Sx))
+
+    def numeric(self, beta=0.0, quick_return_if_not_posdef=False):
+        """Factorize the staged matrix; everything stays in HBM.  Returns CHOLMOD status."""
+        minor = C.c_int64(0)
+        status = C.c_int(0)
+        _check(lib().mi355_factor_numeric(self._h, float(beta), int(bool(quick_return_if_not_posdef)),
+                                          C.byref(minor), C.byref(status)))
+        self.minor, self.status = int(minor.value), int(status.value)
+        return self.status
+
+    def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None):
+        """cholmod_super_numeric(S, NULL, beta, L): S = tril(P A P'), only beta[0] is used
+        (t_cholmod_super_numeric_worker.c:510-520).  Returns Common->status; sets self.minor."""
+        b = beta[0] if isinstance(beta, (tuple, list, np.ndarray)) else beta
+        self.set_matrix(Sp, Si, Sx, Snz)
+        return self.numeric(b, quick_return_if_not_posdef)
+
+    def Lx(self):
+        out = np.zeros(max(self.xsize, 1))
+        _check(lib().mi355_factor_get_Lx(self._h, out))
+        return out[:self.xsize]
+
+    # ---- solves ----
+    def _solve(self, fn, X):
+        X = np.asarray(X, dtype=np.float64)
+        one_d = X.ndim == 1
+        if one_d:
+            X = X[:, None]
+        n, nrhs = X.shape
+        flat = np.ascontiguousarray(X.T).reshape(-1).copy()     # column-major n x nrhs, ld n
+        if flat.size == 0:
+            return X.copy()
+        _check(fn(self._h, nrhs, flat, n))
+        out = flat.reshape(nrhs, n).T.copy()
+        return out[:, 0] if one_d else out
+
+    def super_lsolve(self, X):
+        """x = L \\ b (cholmod_super_lsolve)."""
+        return self._solve(lib().mi355_super_lsolve, X)
+
+    def super_ltsolve(self, X):
+        """x = L' \\ b (cholmod_super_ltsolve)."""
+        return self._solve(lib().mi355_super_ltsolve, X)
+
+    def solve_dev(self, X_ptr, nrhs, d, lower=True):
+        fn = lib().mi355_super_lsolve_dev if lower else lib().mi355_super_ltsolve_dev
+        _check(fn(self._h, int(nrhs), C.c_void_p(int(X_ptr)), int(d)))
+
+    # ---- instrumentation ----
+    def set_profile(self, on=True):
+        _check(lib().mi355_factor_set_profile(self._h, int(bool(on))))
+
+    def stats(self):
+        out = np.zeros(16)
+        _check(lib().mi355_factor_get_stats(self._h, out))
+        return dict(zip(STAT_KEYS, out.tolist()))
+
+    def device_Lx_ptr(self):
+        return lib().mi355_factor_device_Lx(self._h)

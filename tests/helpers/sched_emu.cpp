@@ -1,0 +1,201 @@
+// tests/helpers/sched_emu.cpp -- TEST INFRASTRUCTURE.
+// CPU emulator of the device schedule (suitesparse_amd/csrc/schedule.hpp): executes the
+// very same task lists the HIP kernels consume, with plain loops, so that the HOST logic
+// (levels, task offsets, relative maps, truncated not-posdef rerun, solve sweeps) can be
+// checked against the oracle in the GPU-less container.  Never loaded by the product.
+#include "../../suitesparse_amd/csrc/schedule.hpp"
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+using namespace mi355;
+
+namespace {
+int find_row(const int64_t *a, int64_t len, int64_t key)
+{
+    const int64_t *p = std::lower_bound(a, a + len, key);
+    return (p != a + len && *p == key) ? (int)(p - a) : -1;
+}
+
+struct Emu {
+    Symbolic S;
+    std::vector<double> Dinv;
+    std::vector<int> info;
+};
+
+void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t *Ap, const int64_t *Ai,
+         const double *Ax, double beta, double *Lx, std::vector<double> &Dinv, std::vector<int> &info)
+{
+    std::fill(Lx, Lx + S.xsize, 0.0);
+    info.assign(S.nsuper + 2, 0);
+    Dinv.assign(sc.dinv_size + 1, 0.0);
+    for (int64_t k = 0; k < ncols_asm; k++) {
+        int s = sc.supermap[k];
+        int64_t k1 = S.Super[s], psi = S.Lpi[s], psx = S.Lpx[s], nsrow = S.Lpi[s + 1] - psi;
+        int64_t base = psx + (k - k1) * nsrow;
+        for (int64_t p = Ap[k]; p < Ap[k + 1]; p++) {
+            int64_t i = Ai[p];
+            if (i >= k) { int im = find_row(S.Ls + psi, nsrow, i); if (im >= 0) Lx[base + im] = Ax[p]; }
+        }
+        if (beta != 0) Lx[base + (k - k1)] += beta;
+    }
+    // relative maps
+    std::vector<int32_t> relmap(sc.relmap_size + 1);
+    for (const UpdatePair &u : sc.pairs)
+        for (int i = 0; i < u.ndrow2; i++)
+            relmap[u.rm_off + i] = find_row(S.Ls + u.ls_dst, u.nsrow, S.Ls[u.ls_src + i]);
+    std::vector<double> C;
+    for (const Step &st : sc.steps) {
+        if (st.kind == STEP_POTRF) {
+            for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                const PotrfTask &t = sc.potrf[ti];
+                double *A = Lx + t.a_off; int nb = t.nb; int64_t lda = t.lda;
+                bool failed = false;
+                for (int j = 0; j < nb; j++) {
+                    double d = A[j + j * lda];
+                    if (!(d > 0.0) && !failed) { failed = true; if (info[t.s] == 0) info[t.s] = t.col0 + j + 1; }
+                    double ljj = std::sqrt(d);
+                    A[j + j * lda] = ljj;
+                    for (int i = j + 1; i < nb; i++) A[i + j * lda] /= ljj;
+                    for (int k = j + 1; k < nb; k++)
+                        for (int i = k; i < nb; i++) A[i + k * lda] -= A[i + j * lda] * A[k + j * lda];
+                }
+                double *D = Dinv.data() + t.dinv_off;
+                for (int c = 0; c < nb; c++) {
+                    std::vector<double> x(nb, 0.0); x[c] = 1.0;
+                    for (int k = 0; k < nb; k++) {
+                        x[k] /= A[k + k * lda];
+                        for (int i = k + 1; i < nb; i++) x[i] -= A[i + k * lda] * x[k];
+                    }
+                    for (int i = 0; i < nb; i++) D[i + c * nb] = (i >= c) ? x[i] : 0.0;
+                }
+            }
+        } else {
+            int64_t tiles = 0;
+            for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                const GemmTask &t = sc.gemm[ti];
+                if (t.tile0 != tiles) { info[S.nsuper + 1] = -1; }       // prefix sums must be exact
+                tiles += gemm_tiles(t.M, t.N, t.mode, TILE);
+                const double *A = Lx + t.a_off;
+                const double *B = (t.mode == GEMM_OVERWRITE ? Dinv.data() : Lx) + t.b_off;
+                C.assign((size_t)t.M * t.N, 0.0);
+                for (int k = 0; k < t.K; k++)
+                    for (int n = 0; n < t.N; n++) {
+                        double b = B[n + (int64_t)k * t.ldb];
+                        for (int m = 0; m < t.M; m++) C[m + (size_t)n * t.M] += A[m + (int64_t)k * t.lda] * b;
+                    }
+                double *T = Lx + t.c_off;
+                for (int n = 0; n < t.N; n++)
+                    for (int m = 0; m < t.M; m++) {
+                        double v = C[m + (size_t)n * t.M];
+                        if (t.mode == GEMM_SCATTER_SUB) {
+                            if (m >= n) T[relmap[t.rm_off + m] + (int64_t)relmap[t.rm_off + n] * t.ldc] -= v;
+                        } else if (t.mode == GEMM_DIRECT_SUB) {
+                            if (m >= n) T[m + (int64_t)n * t.ldc] -= v;
+                        } else T[m + (int64_t)n * t.ldc] = v;
+                    }
+            }
+            if (tiles != st.ntiles) info[S.nsuper + 1] = -1;
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them
+int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                      const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                      const double *Ax, double beta, int quick, double *Lx, double *Dinv_out,
+                      int64_t *minor, int *status, int64_t *stats)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    if (!validate_symbolic(S).empty()) return -4;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    std::vector<double> Dinv; std::vector<int> info;
+    run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info);
+    if (info[nsuper + 1] != 0) return -10;
+    if (stats) { stats[0] = sc.nlevels; stats[1] = (int64_t)sc.steps.size(); stats[2] = (int64_t)sc.pairs.size();
+                 stats[3] = sc.relmap_size; stats[4] = sc.dinv_size; stats[5] = (int64_t)sc.gemm.size(); }
+    *status = 0; *minor = n;
+    int64_t sf = -1;
+    for (int64_t s = 0; s < nsuper; s++) if (info[s]) { sf = s; break; }
+    if (sf >= 0) {
+        int inf = info[sf];
+        *status = 1; *minor = Super[sf] + inf - 1;
+        int64_t nscol2 = (inf == 1 || quick) ? 0 : inf - 1;
+        Schedule tr; build_schedule(S, sf, nscol2, tr);
+        std::vector<int> info2;
+        run(S, tr, nscol2 > 0 ? Super[sf + 1] : Super[sf], Ap, Ai, Ax, beta, Lx, Dinv, info2);
+        if (info2[nsuper + 1] != 0) return -11;
+        int64_t nsrow = Lpi[sf + 1] - Lpi[sf];
+        int64_t tail = Lpx[sf] + nsrow * nscol2;
+        std::fill(Lx + tail, Lx + xsize, 0.0);
+    } else if (Dinv_out) {
+        std::copy(Dinv.begin(), Dinv.begin() + sc.dinv_size, Dinv_out);
+    }
+    return 0;
+}
+
+int64_t emu_dinv_size(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                      const int64_t *Ls, int64_t ssize, int64_t xsize)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    return sc.dinv_size;
+}
+
+// the solve sweeps exactly as engine.hip's solve_dev walks the POTRF steps
+int emu_super_solve(int lower, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                    const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
+                    const double *Dinv, int64_t nrhs, double *X, int64_t d)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    std::vector<const Step *> ps;
+    for (const Step &st : sc.steps) if (st.kind == STEP_POTRF) ps.push_back(&st);
+    if (!lower) std::reverse(ps.begin(), ps.end());
+    for (const Step *st : ps) {
+        // row-tile prefix sums must be exact
+        int64_t tiles = 0;
+        for (int64_t ti = st->first; ti < st->first + st->count; ti++) {
+            const PotrfTask &t = sc.potrf[ti];
+            if (t.stile0 != tiles) return -12;
+            tiles += ((int64_t)t.lda - (t.col0 + t.nb) + SOLVE_ROWS - 1) / SOLVE_ROWS;
+        }
+        if (tiles != st->stiles) return -13;
+        for (int phase = 0; phase < 2; phase++) {
+            const bool diag = lower ? (phase == 0) : (phase == 1);
+            for (int64_t ti = st->first; ti < st->first + st->count; ti++) {
+                const PotrfTask &t = sc.potrf[ti];
+                const int nb = t.nb;
+                const double *D = Dinv + t.dinv_off;
+                for (int64_t j = 0; j < nrhs; j++) {
+                    double *x = X + j * d;
+                    double *x1 = x + t.k1 + t.col0;
+                    if (diag) {
+                        std::vector<double> y(nb, 0.0);
+                        for (int i = 0; i < nb; i++)
+                            for (int k = 0; k < nb; k++)
+                                y[i] += (lower ? D[i + k * nb] : D[k + i * nb]) * x1[k];
+                        for (int i = 0; i < nb; i++) x1[i] = y[i];
+                    } else {
+                        for (int r = t.col0 + nb; r < t.lda; r++) {
+                            int64_t row = (r < t.nscol) ? (int64_t)t.k1 + r : Ls[t.ls_off + r];
+                            const double *Lr = Lx + t.a_off + (r - t.col0);
+                            for (int c = 0; c < nb; c++) {
+                                double l = Lr[(int64_t)c * t.lda];
+                                if (lower) x[row] -= l * x1[c]; else x1[c] -= l * x[row];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+}

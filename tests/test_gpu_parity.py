@@ -1,0 +1,201 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(include/mi355_cholmod.h), against the reference's golden outputs and the CPU oracle.
+
+Bars (BASELINE.json north_star): structure is an input (bit-exact by construction);
+max|L_gpu - L_ref| / max|L_ref| <= 1e-10; status / minor / zeroing pattern identical;
+backward error of solves <= 10x the reference's.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, sym_of, relerr
+from test_schedule import backward_error_S
+
+pytestmark = pytest.mark.gpu
+
+TOL_L = 1e-10
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from suitesparse_amd import engine as e
+    assert e.probe() >= 1
+    return e
+
+
+REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
+
+
+@pytest.mark.parametrize("name", REAL)
+def test_golden_factor_and_solve(engine, name):
+    g = load_golden(name)
+    L = engine.SupernodalFactor(sym_of(g))
+    st = L.super_numeric(g["Sp"], g["Si"], g["Sx"], beta=(g["beta"], 0.0))
+    Lx = L.Lx()
+    assert st == g["status"]
+    assert L.minor == g["minor"]
+    assert relerr(Lx, g["Lx"]) < TOL_L
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)      # reference zeroing pattern
+        with pytest.raises(engine.Mi355Error):
+            L.super_lsolve(g["B"])
+        return
+    Y = L.super_lsolve(g["B"])
+    assert relerr(Y, g["Y"]) < 1e-8
+    Z = L.super_ltsolve(Y)
+    assert relerr(Z, g["Z"]) < 1e-8
+    assert backward_error_S(g, Z) <= 10 * backward_error_S(g, g["Z"]) + 1e-18
+    # single right-hand side takes the nrhs == 1 shape of the reference (worker :63-172)
+    y1 = L.super_lsolve(g["B"][:, 0].copy())
+    assert relerr(y1, g["Y"][:, 0]) < 1e-8
+    L.close()
+
+
+@pytest.mark.parametrize("name", ["lap3d_8_npd200", "elast27_4_npd100", "lap2d_16_npd0"])
+def test_quick_return_if_not_posdef(engine, name):
+    from oracle import port
+    g = load_golden(name)
+    sym = sym_of(g)
+    L = engine.SupernodalFactor(sym)
+    st = L.super_numeric(g["Sp"], g["Si"], g["Sx"], quick_return_if_not_posdef=True)
+    so, mo, Lo = port.super_numeric(sym, g["Sp"], g["Si"], g["Sx"], quick_return=True)
+    Lx = L.Lx()
+    assert (st, L.minor) == (so, mo) == (1, g["minor"])
+    assert relerr(Lx, Lo) < TOL_L
+    assert np.array_equal(Lx == 0, Lo == 0)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 256, 257, 300, 700])
+def test_dense_single_supernode(engine, n):
+    """one dense supernode: exercises POTRF blocks, TRSM-by-inverse, inner (K=64) and outer
+    (K=256) trailing updates with ragged edges."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    sym = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n]), Lpi=np.array([0, n]),
+               Lpx=np.array([0, n * n]), Ls=np.arange(n))
+    Sp = np.arange(n + 1, dtype=np.int64) * n
+    Si = np.tile(np.arange(n, dtype=np.int64), n)
+    Sx = np.ascontiguousarray(A.T).reshape(-1)              # full columns; upper entries are ignored
+    L = engine.SupernodalFactor(sym)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    Lg = L.Lx().reshape(n, n).T
+    Lr = np.linalg.cholesky(A)
+    assert np.all(np.triu(Lg, 1) == 0)                      # strictly upper part stays zero (as in the reference)
+    assert relerr(np.tril(Lg), Lr) < TOL_L
+    B = rng.standard_normal((n, 5))
+    X = L.super_ltsolve(L.super_lsolve(B))
+    assert relerr(X, np.linalg.solve(A, B)) < 1e-9
+
+
+def test_two_supernodes_scatter_update(engine):
+    """hand-built arrow structure: supernode 0 = columns 0..39 with rows {0..39} + scattered rows
+    of supernode 1 (columns 40..139): exercises the relative-map scatter with gaps."""
+    from oracle import port
+    n0, n1 = 40, 100
+    n = n0 + n1
+    extra = np.array(sorted(set(range(n0, n, 3)) | {n - 1}), dtype=np.int64)
+    rows0 = np.concatenate([np.arange(n0), extra])
+    rows1 = np.arange(n0, n)
+    sym = dict(n=n, nsuper=2, Super=np.array([0, n0, n]), Lpi=np.array([0, len(rows0), len(rows0) + n1]),
+               Lpx=np.array([0, len(rows0) * n0, len(rows0) * n0 + n1 * n1]), Ls=np.concatenate([rows0, rows1]))
+    sym["ssize"] = len(sym["Ls"])
+    sym["xsize"] = int(sym["Lpx"][-1])
+    sym["maxcsize"] = len(extra) ** 2
+    rng = np.random.default_rng(7)
+    A = np.zeros((n, n))
+    A[np.ix_(rows0, np.arange(n0))] = rng.standard_normal((len(rows0), n0))
+    A[n0:, n0:] = rng.standard_normal((n1, n1))
+    A = np.tril(A)
+    A = A + A.T
+    A += np.eye(n) * (np.abs(A).sum(1).max() + 1)
+    import scipy.sparse as sp
+    S = sp.csc_matrix(np.tril(A))
+    S.sort_indices()
+    Sp, Si, Sx = S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data
+    L = engine.SupernodalFactor(sym)
+    st = L.super_numeric(Sp, Si, Sx)
+    so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx)
+    assert st == so == 0
+    assert relerr(L.Lx(), Lo) < TOL_L
+
+
+@pytest.mark.parametrize("kind,size,ordering", [("lap3d", 24, "metis"), ("lap2d", 150, "metis"),
+                                                ("elast", 10, "metis"), ("lap3d", 20, "amd")])
+def test_vs_live_reference(engine, kind, size, ordering, have_ref):
+    """mid-size problems (supernodes > 256 wide, ~12 levels): reference CPU worker in the same run"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d,
+         "elast": problems.elasticity27}[kind](size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze(ordering)
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    L = engine.SupernodalFactor(sym)
+    assert L.super_numeric(Sp, Si, Sx) == 0 and L.minor == p["n"]
+    Lx = L.Lx()
+    assert relerr(Lx, r.Lx()) < TOL_L
+    # refactorize with new values on the same handle (cholmod_super_numeric.c:27-31)
+    assert L.super_numeric(Sp, Si, 2.0 * Sx) == 0
+    assert relerr(L.Lx(), np.sqrt(2.0) * r.Lx()) < TOL_L
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    B = problems.demo_rhs(p["n"], 3)
+    Bp = B[sym["Perm"]]
+    Xg = L.super_ltsolve(L.super_lsolve(Bp))
+    Xr = r.super_solve(r.super_solve(Bp, True), False)
+    assert relerr(Xg, Xr) < 1e-9
+    X = np.empty_like(Xg)
+    X[sym["Perm"]] = Xg
+    bg = problems.backward_error(p, X, B)
+    br = problems.backward_error(p, r.solve(B), B)
+    assert bg <= 10 * br + 1e-18
+    # drop-in: the reference's own cholmod_l_solve runs on the GPU-computed factor
+    r.set_Lx(Lx)
+    assert problems.backward_error(p, r.solve(B), B) <= 10 * br + 1e-18
+
+
+def test_error_paths(engine):
+    """argument checking in the spirit of CHOLMOD/Tcov/t_raw_factor.c:155-346"""
+    g = load_golden("demo_bcsstk01")
+    sym = sym_of(g)
+    bad = dict(sym)
+    bad["Lpx"] = sym["Lpx"].copy()
+    bad["Lpx"][3] += 1
+    with pytest.raises(engine.Mi355Error) as ei:
+        engine.SupernodalFactor(bad)
+    assert ei.value.code == engine.CHOLMOD_INVALID
+    bad = dict(sym)
+    bad["Ls"] = sym["Ls"].copy()
+    bad["Ls"][5], bad["Ls"][6] = bad["Ls"][6], bad["Ls"][5]          # unsorted rows
+    with pytest.raises(engine.Mi355Error):
+        engine.SupernodalFactor(bad)
+    with pytest.raises(engine.Mi355Error) as ei:
+        engine.SupernodalFactor(sym, xtype=2)                        # complex: CPU worker's job for now
+    assert ei.value.code == engine.CHOLMOD_NOT_INSTALLED
+    L = engine.SupernodalFactor(sym)
+    with pytest.raises(engine.Mi355Error):
+        L.numeric()                                                  # no matrix staged
+    with pytest.raises(engine.Mi355Error):
+        L.super_lsolve(g["B"])                                       # no numeric factor yet
+    Si = g["Si"].copy()
+    Si[0] = g["n"] + 3
+    with pytest.raises(engine.Mi355Error):
+        L.set_matrix(g["Sp"], Si, g["Sx"])                           # row index out of range
+    assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == 0
+    with pytest.raises(engine.Mi355Error):
+        L.super_lsolve(np.zeros((g["n"] + 1, 1)))                    # dimension mismatch
+
+
+def test_empty_factor(engine):
+    sym = dict(n=0, nsuper=0, ssize=0, xsize=0, Super=np.zeros(1, np.int64), Lpi=np.zeros(1, np.int64),
+               Lpx=np.zeros(1, np.int64), Ls=np.zeros(0, np.int64))
+    L = engine.SupernodalFactor(sym)
+    assert L.super_numeric(np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0)) == 0
+    assert L.minor == 0

@@ -1,0 +1,96 @@
+"""CPU tests of the HOST logic of the product: the level schedule (suitesparse_amd/csrc/
+schedule.cpp) executed by the CPU emulator tests/helpers/sched_emu.cpp must reproduce the
+reference's factor, status, minor, zeroing pattern and solves on the golden fixtures."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden, sym_of, relerr
+
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    E = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    E.emu_super_numeric.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p,
+                                    i64p, f64p, C.c_double, C.c_int, f64p, f64p, i64p, C.POINTER(C.c_int), i64p]
+    E.emu_dinv_size.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64]
+    E.emu_dinv_size.restype = C.c_int64
+    E.emu_super_solve.argtypes = [C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
+                                  f64p, f64p, C.c_int64, f64p, C.c_int64]
+    return E
+
+
+def run_emu(E, g, quick=0):
+    a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+    ds = E.emu_dinv_size(*a)
+    Lx = np.zeros(g["xsize"])
+    D = np.zeros(ds + 1)
+    minor = np.zeros(1, dtype=np.int64)
+    st = C.c_int(0)
+    stats = np.zeros(8, dtype=np.int64)
+    rc = E.emu_super_numeric(*a, g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64), g["beta"],
+                             quick, Lx, D, minor, C.byref(st), stats)
+    assert rc == 0
+    return st.value, int(minor[0]), Lx, D
+
+
+def backward_error_S(g, X):
+    """||S x - b|| / (||S|| ||x|| + ||b||) for the permuted system (cholmod_dl_demo.c:614-617)"""
+    import scipy.sparse as sp
+    n = g["n"]
+    S = sp.csc_matrix((g["Sx"], g["Si"], g["Sp"]), shape=(n, n))
+    A = (S + S.conj().T - sp.diags(S.diagonal())).tocsr()
+    if g["beta"]:
+        A = A + g["beta"] * sp.identity(n)
+    R = A @ X - g["B"]
+    return float(np.abs(R).max() / (abs(A).sum(axis=1).max() * np.abs(X).max() + np.abs(g["B"]).max()))
+
+
+REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
+
+
+@pytest.mark.parametrize("name", REAL)
+def test_schedule_reproduces_reference(emu, name):
+    g = load_golden(name)
+    st, minor, Lx, D = run_emu(emu, g)
+    assert st == g["status"] and minor == g["minor"]
+    assert relerr(Lx, g["Lx"]) < 1e-12
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+        return
+    a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+    n, nrhs = g["B"].shape
+    X = np.ascontiguousarray(g["B"].T).reshape(-1).copy()
+    assert emu.emu_super_solve(1, *a, Lx, D, nrhs, X, n) == 0
+    # the block-inverse diagonal solves differ from substitution by cond(L11)*eps in the
+    # forward error (tcov_ex5lo: cond(A) = 6.6e7); the backward error is the contract
+    assert relerr(X.reshape(nrhs, n).T, g["Y"]) < 1e-8
+    assert emu.emu_super_solve(0, *a, Lx, D, nrhs, X, n) == 0
+    Z = X.reshape(nrhs, n).T
+    assert relerr(Z, g["Z"]) < 1e-8
+    assert backward_error_S(g, Z) <= 10 * backward_error_S(g, g["Z"]) + 1e-18
+
+
+def test_schedule_large_supernodes_vs_oracle(emu, have_ref):
+    """two-level blocking (nscol > 256) and many levels: 3D 24^3 through the live reference"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = problems.laplacian_3d(24)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    assert np.diff(sym["Super"]).max() > 256
+    g = dict(sym, Sp=Sp, Si=Si, Sx=Sx, beta=0.0)
+    st, minor, Lx, _ = run_emu(emu, g)
+    assert st == 0 and minor == p["n"]
+    assert relerr(Lx, r.Lx()) < 1e-12
