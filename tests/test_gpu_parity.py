@@ -189,8 +189,9 @@ def test_error_paths(engine):
     with pytest.raises(engine.Mi355Error):
         L.set_matrix(g["Sp"], Si, g["Sx"])                           # row index out of range
     assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == 0
-    with pytest.raises(engine.Mi355Error):
-        L.super_lsolve(np.zeros((g["n"] + 1, 1)))                    # dimension mismatch
+    x = np.zeros(g["n"])
+    with pytest.raises(engine.Mi355Error):                           # d < n: "X and L dimensions must match"
+        engine._check(engine.lib().mi355_super_lsolve(L._h, 1, x, g["n"] - 1))
 
 
 def test_empty_factor(engine):
