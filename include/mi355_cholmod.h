@@ -126,6 +126,10 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *            15 reserved */
 int mi355_factor_get_stats(mi355_factor *handle, double *out16);
 
+/* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device`, in TFLOP/s (no counterpart
+ * in the reference; used by bench.py to state the FP64 matrix peak next to the vendor figure). */
+int mi355_debug_mfma_f64_rate(int device, double *tflops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ struct DeviceSchedule {
 
 }  // namespace
 
+namespace { struct EventTimer; }
 struct mi355_factor_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -97,6 +98,7 @@ struct mi355_factor_s {
     int profile = 0;
     double st_total = 0, st_gemm = 0, st_potrf = 0, st_asm = 0, st_solve = 0;
     double st_ngemm = 0, st_npotrf = 0, st_tiles = 0;
+    EventTimer *timer = nullptr;   // events of the last profiled numeric call, collected lazily
 };
 
 namespace {
@@ -154,6 +156,15 @@ struct EventTimer {
     {
         if (!on) return;
         (void)hipEventRecord(ev[kind].back().second, st);
+    }
+    bool pending = false;
+    void drop()
+    {
+        for (int k = 0; k < 3; k++) {
+            for (auto &p : ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+            ev[k].clear();
+        }
+        pending = false;
     }
     double collect(int kind)
     {
@@ -295,6 +306,7 @@ int mi355_factor_free(mi355_factor *F)
     if (!F) return MI355_OK;
     (void)hipSetDevice(F->device);
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
+    if (F->timer) { F->timer->drop(); delete F->timer; }
     delete F;
     return MI355_OK;
 }
@@ -344,7 +356,9 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
         if (status) *status = MI355_STATUS_OK;
         return MI355_OK;
     }
-    EventTimer tm;
+    if (!F->timer) F->timer = new EventTimer;
+    EventTimer &tm = *F->timer;
+    tm.drop();
     tm.on = F->profile != 0;
     tm.st = F->stream;
     hipEvent_t e0, e1;
@@ -392,7 +406,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     F->st_total = ms;
-    if (tm.on) { F->st_gemm = tm.collect(0); F->st_potrf = tm.collect(1); F->st_asm = tm.collect(2); }
+    tm.pending = tm.on;
     F->minor = minor_out;
     F->numeric_ok = (st_out == MI355_STATUS_OK);
     if (minor) *minor = minor_out;
@@ -519,10 +533,57 @@ int mi355_factor_set_profile(mi355_factor *F, int profile)
     return MI355_OK;
 }
 
+// bare v_mfma_f64_16x16x4_f64 issue-rate probe: 4 independent accumulators per wave, operands in
+// registers, 4 waves per workgroup (one per SIMD), 2 workgroups per CU
+__global__ __launch_bounds__(256) void k_mfma_rate(int iters, double *out)
+{
+    v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; i++) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    v4d s = a0 + a1 + a2 + a3;
+    if (s[0] + s[1] + s[2] + s[3] == 123.456) out[0] = s[0];
+}
+
+int mi355_debug_mfma_f64_rate(int device, double *tflops)
+{
+    g_err.clear();
+    if (!tflops) return fail(MI355_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    DevBuf<double> d;
+    HIP_TRY(d.alloc(1));
+    const int iters = 20000, grid = prop.multiProcessorCount * 2;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mfma_rate, dim3(grid), dim3(256), 0, 0, 100, d.p);       // warm-up
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_mfma_rate, dim3(grid), dim3(256), 0, 0, iters, d.p);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double flops = (double)grid * 4 /*waves*/ * iters * 4.0 /*mfma per iter*/ * 2048.0;
+    *tflops = flops / (ms * 1e-3) * 1e-12;
+    return MI355_OK;
+}
+
 int mi355_factor_get_stats(mi355_factor *F, double *out)
 {
     if (!F || !out) return fail(MI355_INVALID, "null argument");
     const Schedule &S = F->full.sched;
+    if (F->timer && F->timer->pending) {
+        (void)hipSetDevice(F->device);
+        F->st_gemm = F->timer->collect(0); F->st_potrf = F->timer->collect(1); F->st_asm = F->timer->collect(2);
+        F->timer->pending = false;
+    }
     out[0] = F->st_total; out[1] = F->st_gemm; out[2] = F->st_ngemm; out[3] = F->st_potrf;
     out[4] = F->st_npotrf; out[5] = F->st_asm; out[6] = S.flops_update; out[7] = S.flops_panel;
     out[8] = S.bytes_assembly; out[9] = (double)S.pairs.size(); out[10] = (double)S.nlevels;

@@ -32,7 +32,7 @@ EXPORTS = [
     "mi355_factor_set_matrix", "mi355_factor_numeric", "mi355_factor_get_Lx",
     "mi355_super_numeric", "mi355_super_lsolve", "mi355_super_ltsolve",
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
-    "mi355_factor_set_profile", "mi355_factor_get_stats",
+    "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
 ]
 
 _LIB = None
@@ -82,6 +82,14 @@ def _check(rc):
 
 def probe():
     return lib().mi355_probe()
+
+
+def mfma_f64_rate(device=0):
+    """measured TFLOP/s of bare v_mfma_f64_16x16x4_f64 issue on `device`"""
+    out = C.c_double(0.0)
+    lib().mi355_debug_mfma_f64_rate.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    _check(lib().mi355_debug_mfma_f64_rate(int(device), C.byref(out)))
+    return out.value
 
 
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",

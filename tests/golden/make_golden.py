@@ -24,9 +24,9 @@ REF = "/root/reference/CHOLMOD"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def record(name, r, ordering, note, beta=0.0):
+def record(name, r, ordering, note, beta=0.0, user_perm=None):
     m = r.matrix()
-    inf = r.analyze(ordering)
+    inf = r.analyze(ordering, perm=user_perm)
     if not inf["is_super"]:
         raise RuntimeError("not supernodal")
     sym = r.symbolic()
@@ -44,6 +44,8 @@ def record(name, r, ordering, note, beta=0.0):
                Perm=sym["Perm"], ColCount=sym["ColCount"], Super=sym["Super"], Lpi=sym["Lpi"],
                Lpx=sym["Lpx"], Ls=sym["Ls"], Sp=Sp, Si=Si, Sx=Sx, Lx=Lx, status=status,
                minor=inf["minor"], B=B)
+    if user_perm is not None:
+        out["UserPerm"] = np.asarray(user_perm, dtype=np.int64)
     if status == 0:
         Y = r.super_solve(B, True)
         Z = r.super_solve(Y, False)
@@ -63,7 +65,7 @@ def from_file(name, path, ordering="default", note=""):
     record(name, r, ordering, note or f"reference fixture {os.path.relpath(path, '/root/reference')}")
 
 
-def from_problem(name, p, ordering, note, negate_col=None, beta=0.0):
+def from_problem(name, p, ordering, note, negate_col=None, beta=0.0, user_perm=None):
     r = RefCholmod()
     Ax = p["Ax"].copy()
     if negate_col is not None:
@@ -71,7 +73,7 @@ def from_problem(name, p, ordering, note, negate_col=None, beta=0.0):
         assert p["Ai"][d] == negate_col
         Ax[d] = -abs(Ax[d])
     r.load(p["n"], p["Ap"], p["Ai"], Ax, -1)
-    record(name, r, ordering, note, beta=beta)
+    record(name, r, ordering, note, beta=beta, user_perm=user_perm)
 
 
 if __name__ == "__main__":
@@ -89,6 +91,11 @@ if __name__ == "__main__":
     from_problem("lap2d_16_nesdis", problems.laplacian_2d(16), "nesdis", "2D 5-pt 16^2, NESDIS")
     from_problem("elast27_4_metis", problems.elasticity27(4), "metis", "27-pt 3-dof 4^3, METIS")
     from_problem("helm3d_6_metis", problems.helmholtz_3d(6), "metis", "complex Hermitian 6^3, METIS")
+    from suitesparse_amd import symbolic
+    for nm, p in (("nd_lap3d_9", problems.laplacian((9, 8, 7))), ("nd_lap2d_20", problems.laplacian((20, 17))),
+                  ("nd_elast27_4", problems.elasticity27(4))):
+        from_problem(nm, p, "given", nm + ": CHOLMOD_GIVEN with the geometric ND permutation (UserPerm)",
+                     user_perm=symbolic.nd_grid_order(p["shape"], p["dof"]))
     from_problem("lap3d_8_natural", problems.laplacian_3d(8), "natural", "3D 7-pt 8^3, natural ordering")
     from_problem("lap3d_8_beta", problems.laplacian_3d(8), "metis", "3D 7-pt 8^3, METIS, beta=0.5", beta=0.5)
     from_problem("lap3d_8_npd200", problems.laplacian_3d(8), "metis",

@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT, load_golden, sym_of
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mi355_cholmod.h")).read()
+def declared_symbols(header="mi355_cholmod.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mi355_[a-z_A-Z0-9]+)\s*\(", txt)))
 
@@ -24,6 +24,11 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/mi355_cholmod.h but not exported"
     assert set(syms) == set(engine.EXPORTS)
+    from suitesparse_amd import symbolic
+    syms2 = declared_symbols("mi355_symbolic.h")
+    for s in syms2:
+        assert hasattr(L, s), f"{s} declared in include/mi355_symbolic.h but not exported"
+    assert set(syms2) == set(symbolic.EXPORTS)
 
 
 def test_no_cpu_fallback_without_gpu():
