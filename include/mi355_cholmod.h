@@ -92,6 +92,22 @@ int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *
                         int quick_return_if_not_posdef, double *Lx,
                         int64_t *minor, int *status);
 
+/* ---- multi-GPU phases (no counterpart in the reference, which uses one device:
+ *      CHOLMOD/GPU/cholmod_gpu.c:138-142).  Masks have nsuper entries.
+ *      local_mask: supernodes of the subtrees this rank owns; top_mask: the shared top
+ *      supernodes (every rank factorizes them after the reduction); asm_mask: supernodes whose
+ *      columns of S this rank assembles (own subtrees, plus the top on exactly one rank).
+ *      phase 0: zero Lx, assemble, factorize the own subtrees and accumulate their updates
+ *               (also into this rank's copy of the top panels);
+ *      [caller sums the top panels' Lx ranges over the ranks: RCCL all-reduce]
+ *      phase 1: factorize the top supernodes.
+ *      *first_bad = first supernode whose pivot failed in that phase (-1: none), *info = LAPACK
+ *      info inside it.  The repeat-supernode protocol is not replayed on this path. */
+int mi355_factor_set_partition(mi355_factor *handle, const int8_t *local_mask,
+                               const int8_t *top_mask, const int8_t *asm_mask);
+int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,
+                               int64_t *first_bad, int64_t *info);
+
 /* ---- supernodal triangular solves: replace cholmod_l_super_lsolve / _ltsolve
  *      (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153; workers
  *      t_cholmod_super_solve_worker.c:20-303,309-580).  X is n x nrhs, column-major,

@@ -88,6 +88,9 @@ struct mi355_factor_s {
     DevBuf<int64_t> dSuper, dLpi, dLpx;
     DevBuf<int> info;           // nsuper + 2 (first-failure scratch at [nsuper], [nsuper+1])
     DeviceSchedule full;
+    // multi-GPU partition: own subtrees / shared top, see mi355_factor_set_partition
+    DeviceSchedule *part_local = nullptr, *part_top = nullptr;
+    DevBuf<int8_t> asm_mask;
     // staged matrix
     DevBuf<int64_t> Ap, Ai, Anz;
     DevBuf<double> Ax;
@@ -182,17 +185,20 @@ struct EventTimer {
 };
 
 // run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
-int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm)
+int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm,
+                 const int8_t *smask = nullptr, bool init = true)
 {
     const Symbolic &S = F->sym;
     tm.begin(2);
-    HIP_TRY(hipMemsetAsync(F->Lx.p, 0, (size_t)S.xsize * sizeof(double), F->stream));
-    HIP_TRY(hipMemsetAsync(F->info.p, 0, (size_t)(S.nsuper + 2) * sizeof(int), F->stream));
-    if (ncols_asm > 0) {
+    if (init) {
+        HIP_TRY(hipMemsetAsync(F->Lx.p, 0, (size_t)S.xsize * sizeof(double), F->stream));
+        HIP_TRY(hipMemsetAsync(F->info.p, 0, (size_t)(S.nsuper + 2) * sizeof(int), F->stream));
+    }
+    if (init && ncols_asm > 0) {
         const unsigned grid = (unsigned)((ncols_asm + 255) / 256);
         hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm, F->Ap.p, F->Ai.p,
                            F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
-                           F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta);
+                           F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta, smask);
         HIP_TRY(hipGetLastError());
     }
     tm.end(2);
@@ -307,6 +313,8 @@ int mi355_factor_free(mi355_factor *F)
     (void)hipSetDevice(F->device);
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
     if (F->timer) { F->timer->drop(); delete F->timer; }
+    delete F->part_local;
+    delete F->part_top;
     delete F;
     return MI355_OK;
 }
@@ -436,6 +444,78 @@ int mi355_super_numeric(mi355_factor *F, const int64_t *Ap, const int64_t *Ai, c
     rc = mi355_factor_numeric(F, beta_re, quick_return_if_not_posdef, minor, status);
     if (rc) return rc;
     return mi355_factor_get_Lx(F, Lx);
+}
+
+int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const int8_t *top_mask,
+                               const int8_t *asm_mask)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!local_mask || !top_mask || !asm_mask) return fail(MI355_INVALID, "null mask");
+    const Symbolic &S = F->sym;
+    for (int64_t s = 0; s < S.nsuper; s++)
+        if (local_mask[s] && top_mask[s]) return fail(MI355_INVALID, "a supernode is both local and top");
+    delete F->part_local; F->part_local = nullptr;
+    delete F->part_top; F->part_top = nullptr;
+    F->part_local = new DeviceSchedule;
+    F->part_top = new DeviceSchedule;
+    build_schedule(S, S.nsuper, 0, F->part_local->sched, local_mask);
+    build_schedule(S, S.nsuper, 0, F->part_top->sched, top_mask);
+    rc = upload_schedule(F, *F->part_local);
+    if (rc) return rc;
+    rc = upload_schedule(F, *F->part_top);
+    if (rc) return rc;
+    HIP_TRY(F->asm_mask.upload(asm_mask, (size_t)S.nsuper, F->stream));
+    return MI355_OK;
+}
+
+int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64_t *first_bad, int64_t *info_out)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_local || !F->part_top) return fail(MI355_INVALID, "mi355_factor_set_partition was not called");
+    if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
+    if (phase != 0 && phase != 1) return fail(MI355_INVALID, "phase must be 0 (own subtrees) or 1 (top)");
+    const Symbolic &S = F->sym;
+    F->numeric_ok = false;
+    if (first_bad) *first_bad = -1;
+    if (info_out) *info_out = 0;
+    if (S.nsuper == 0) return MI355_OK;
+    if (!F->timer) F->timer = new EventTimer;
+    EventTimer &tm = *F->timer;
+    if (phase == 0) { tm.drop(); F->st_ngemm = F->st_npotrf = F->st_tiles = 0; }
+    tm.on = F->profile != 0;
+    tm.st = F->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, F->stream));
+    rc = run_schedule(F, phase == 0 ? *F->part_local : *F->part_top, S.n, beta_re, tm, F->asm_mask.p, phase == 0);
+    if (rc) return rc;
+    int *first = F->info.p + S.nsuper;
+    const int big = 0x7f7f7f7f;
+    HIP_TRY(hipMemsetAsync(first, 0x7f, sizeof(int), F->stream));
+    hipLaunchKernelGGL(k_first_info, dim3((unsigned)((S.nsuper + 255) / 256)), dim3(256), 0, F->stream,
+                       S.nsuper, F->info.p, first);
+    HIP_TRY(hipGetLastError());
+    int sf = big;
+    HIP_TRY(hipMemcpyAsync(&sf, first, sizeof(int), hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipEventRecord(e1, F->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    F->st_total = (phase == 0 ? 0.0 : F->st_total) + ms;
+    tm.pending = tm.on;
+    if (sf != big) {
+        int info = 0;
+        HIP_TRY(hipMemcpy(&info, F->info.p + sf, sizeof(int), hipMemcpyDeviceToHost));
+        if (first_bad) *first_bad = sf;
+        if (info_out) *info_out = info;
+    }
+    return MI355_OK;
 }
 
 static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d)

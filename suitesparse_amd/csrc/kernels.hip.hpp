@@ -46,11 +46,13 @@ __global__ __launch_bounds__(256) void k_assemble(
     const int64_t *__restrict__ Anz, const double *__restrict__ Ax,
     const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
     const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx,
-    const int32_t *__restrict__ Ls, double *__restrict__ Lx, double beta)
+    const int32_t *__restrict__ Ls, double *__restrict__ Lx, double beta,
+    const int8_t *__restrict__ smask)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncols) return;
     const int s = supermap[k];
+    if (smask && !smask[s]) return;
     const int64_t k1 = Super[s], psi = Lpi[s], psx = Lpx[s];
     const int nsrow = (int)(Lpi[s + 1] - psi);
     const int64_t colbase = psx + (k - k1) * (int64_t)nsrow;

@@ -94,7 +94,8 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level)
 
 }  // namespace
 
-void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out)
+void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
+                    const int8_t *mask)
 {
     out = Schedule();
     const int64_t ns = S.nsuper;
@@ -131,6 +132,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     std::vector<LevelSteps> L(nlev);
 
     for (int64_t s = 0; s < s_end; s++) {
+        if (mask && !mask[s]) continue;
         const int lev = out.level[s];
         const int64_t nscol = S.Super[s + 1] - S.Super[s];
         const int64_t nsrow = S.Lpi[s + 1] - S.Lpi[s];

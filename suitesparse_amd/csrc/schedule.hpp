@@ -113,7 +113,10 @@ std::string validate_symbolic(const Symbolic &S);
 // Full schedule: s_limit = nsuper.  Truncated schedule for the not-posdef repeat:
 // supernodes < s_limit are processed completely, supernode s_limit only in its first
 // nscol2_limit columns (0: not at all), later supernodes not at all.
-void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out);
+// mask (optional, nsuper entries): only supernodes with mask[s] != 0 get their panel factorized
+// and push their updates -- the multi-GPU phases (own subtrees / shared top) of SURVEY 8(e).
+void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
+                    const int8_t *mask = nullptr);
 
 // number of TILE-tiles of one task
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile);

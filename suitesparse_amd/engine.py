@@ -33,6 +33,7 @@ EXPORTS = [
     "mi355_super_numeric", "mi355_super_lsolve", "mi355_super_ltsolve",
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
+    "mi355_factor_set_partition", "mi355_factor_numeric_phase",
 ]
 
 _LIB = None
@@ -71,6 +72,10 @@ def lib():
         L.mi355_factor_device_Lx.restype = C.c_void_p
         L.mi355_factor_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.mi355_factor_get_stats.argtypes = [C.c_void_p, _f64p]
+        _i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+        L.mi355_factor_set_partition.argtypes = [C.c_void_p, _i8p, _i8p, _i8p]
+        L.mi355_factor_numeric_phase.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int64)]
         _LIB = L
     return _LIB
 
@@ -192,6 +197,32 @@ class SupernodalFactor:
     def solve_dev(self, X_ptr, nrhs, d, lower=True):
         fn = lib().mi355_super_lsolve_dev if lower else lib().mi355_super_ltsolve_dev
         _check(fn(self._h, int(nrhs), C.c_void_p(int(X_ptr)), int(d)))
+
+    # ---- multi-GPU phases (see suitesparse_amd/multigpu.py) ----
+    def set_partition(self, local_mask, top_mask, asm_mask):
+        m = [np.ascontiguousarray(a, dtype=np.int8) for a in (local_mask, top_mask, asm_mask)]
+        _check(lib().mi355_factor_set_partition(self._h, *m))
+
+    def numeric_phase(self, phase, beta=0.0):
+        """returns (first_bad_supernode or -1, info)"""
+        bad = C.c_int64(-1)
+        info = C.c_int64(0)
+        _check(lib().mi355_factor_numeric_phase(self._h, int(phase), float(beta), C.byref(bad), C.byref(info)))
+        return int(bad.value), int(info.value)
+
+    def top_tensors(self, ranges):
+        """torch views of Lx[lo:hi) for each (lo, hi) (device memory, no copy)"""
+        import torch
+        base = self.device_Lx_ptr()
+        out = []
+        for lo, hi in ranges:
+            class _View:
+                pass
+            v = _View()
+            v.__cuda_array_interface__ = {"shape": (int(hi - lo),), "typestr": "<f8", "data": (base + 8 * int(lo), False),
+                                          "version": 2}
+            out.append(torch.as_tensor(v, device="cuda"))
+        return out
 
     # ---- instrumentation ----
     def set_profile(self, on=True):

@@ -1,0 +1,154 @@
+"""Subtree-to-GPU partitioning of the supernodal factorization.
+
+The reference has no multi-device path (CHOLMOD/GPU/cholmod_gpu.c:138-142 uses one GPU);
+this is new work.  One process per GPU:
+
+  1. partition(): supernodes are split into a shared TOP set (ancestors of the cut) and
+     disjoint subtrees below it; subtrees are assigned to ranks by LPT on their flop
+     weight.  Postordering makes every subtree a contiguous supernode range and a
+     contiguous slab of Lx.
+  2. phase 0 (per rank): assemble + factorize the own subtrees; their Schur-complement
+     contributions to top supernodes accumulate in this rank's copy of the top panels
+     (rank 0's copy also holds the entries of A).
+  3. ONE sum all-reduce over the Lx ranges of the top supernodes (RCCL over xGMI; adjacent
+     top supernodes are coalesced into a single range).
+  4. phase 1: every rank factorizes the top supernodes (replicated).
+
+No collective sits inside the data path of a subtree.  The replicated top bounds the speed-up
+(SURVEY Appendix A.3); distributing the top fronts block-cyclically is the next step.
+"""
+import numpy as np
+
+
+def supernode_tree(sym):
+    """parent[] of the supernodal etree (parent = SuperMap[Ls[psi+nscol]],
+    t_cholmod_super_numeric_worker.c:1226) and the per-supernode flop weight
+    nscol^3/3 + nsrow2*nscol^2 (POTRF+TRSM) + nscol*nsrow2^2 (all updates it pushes)."""
+    Super, Lpi, Ls = sym["Super"], sym["Lpi"], sym["Ls"]
+    ns = int(sym["nsuper"])
+    n = int(sym["n"])
+    nscol = np.diff(Super).astype(np.int64)
+    nsrow = np.diff(Lpi).astype(np.int64)
+    supermap = np.repeat(np.arange(ns, dtype=np.int64), nscol)
+    assert supermap.size == n
+    parent = np.full(ns, -1, dtype=np.int64)
+    has = nsrow > nscol
+    first_below = Ls[(Lpi[:-1] + nscol)[has]]
+    parent[has] = supermap[first_below]
+    c = nscol.astype(np.float64)
+    r2 = (nsrow - nscol).astype(np.float64)
+    work = c ** 3 / 3.0 + r2 * c * c + c * r2 * r2
+    return parent, work
+
+
+def partition(sym, world, min_subtrees_per_rank=4):
+    """Returns dict(owner[nsuper] (-1 = top), top_ranges [(lo,hi) Lx offsets], stats)."""
+    ns = int(sym["nsuper"])
+    parent, work = supernode_tree(sym)
+    sub = work.copy()
+    first = np.arange(ns, dtype=np.int64)            # first (lowest) supernode of each subtree
+    children = [[] for _ in range(ns)]
+    for s in range(ns):                              # parent[s] > s (postorder)
+        p = parent[s]
+        if p >= 0:
+            sub[p] += sub[s]
+            first[p] = min(first[p], first[s])
+            children[p].append(s)
+    total = float(work.sum())
+    owner = np.full(ns, -1, dtype=np.int64)
+    if world <= 1:
+        owner[:] = 0
+        return dict(owner=owner, top_ranges=[], top_work=0.0, rank_work=[total], total_work=total)
+    import heapq
+    heap = [(-sub[s], s) for s in range(ns) if parent[s] < 0]
+    heapq.heapify(heap)
+    target = total / (2.0 * world)
+    top = []
+    while heap:
+        w, s = heap[0]
+        enough = len(heap) >= min_subtrees_per_rank * world
+        if (-w <= target and enough) or not children[s]:
+            break                                    # balanced enough, or the heaviest subtree is a leaf
+        heapq.heappop(heap)
+        top.append(s)
+        for c in children[s]:
+            heapq.heappush(heap, (-sub[c], c))
+    # LPT assignment of the remaining subtrees
+    loads = [0.0] * world
+    for w, s in sorted(heap):
+        r = int(np.argmin(loads))
+        loads[r] += -w
+        owner[first[s]:s + 1] = r                    # contiguous: a postordered subtree
+    for s in top:
+        owner[s] = -1
+    Lpx = sym["Lpx"]
+    ranges = []
+    for s in sorted(top):
+        lo, hi = int(Lpx[s]), int(Lpx[s + 1])
+        if ranges and ranges[-1][1] == lo:
+            ranges[-1] = (ranges[-1][0], hi)
+        else:
+            ranges.append((lo, hi))
+    return dict(owner=owner, top_ranges=ranges, top_work=float(work[top].sum()) if top else 0.0,
+                rank_work=loads, total_work=total)
+
+
+class PartitionedFactor:
+    """Drives the two phases + the reduction.  `factor` is a suitesparse_amd.engine.SupernodalFactor
+    (or any object with set_partition / numeric_phase / top_tensors); `allreduce(tensors)` sums
+    every tensor over the ranks (default: torch.distributed all_reduce = RCCL on GPUs)."""
+
+    def __init__(self, factor, sym, rank, world, allreduce=None, min_subtrees_per_rank=4):
+        self.f, self.rank, self.world = factor, rank, world
+        self.n = int(sym["n"])
+        self.Super = sym["Super"]
+        self.part = partition(sym, world, min_subtrees_per_rank)
+        owner = self.part["owner"]
+        local = (owner == rank).astype(np.int8)
+        top = (owner < 0).astype(np.int8)
+        asm = local.copy()
+        if rank == 0:
+            asm |= top
+        factor.set_partition(local, top, asm)
+        self.tensors = factor.top_tensors(self.part["top_ranges"])
+        self.allreduce = allreduce or self._dist_allreduce
+        self.status, self.minor = 0, self.n
+
+    @staticmethod
+    def _dist_allreduce(tensors):
+        import torch.distributed as dist
+        work = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in tensors]
+        for w in work:
+            w.wait()
+        if tensors and tensors[0].is_cuda:
+            # the engine launches on its own (non-blocking) HIP stream: phase 1 must not start
+            # before the collective has finished on the communication stream
+            import torch
+            torch.cuda.synchronize()
+
+    def _agree(self, bad, info):
+        """smallest failing supernode over the ranks -> (status, minor)"""
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            dev = self.tensors[0].device if self.tensors else "cpu"
+            key = torch.tensor([bad if bad >= 0 else 2 ** 62], dtype=torch.int64, device=dev)
+            dist.all_reduce(key, op=dist.ReduceOp.MIN)
+            gbad = int(key.item())
+            inf = torch.tensor([info if (bad == gbad) else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(inf, op=dist.ReduceOp.MAX)
+            bad, info = (gbad if gbad < 2 ** 62 else -1), int(inf.item())
+        if bad >= 0:
+            self.status, self.minor = 1, int(self.Super[bad]) + info - 1
+        return bad
+
+    def numeric(self, beta=0.0):
+        self.status, self.minor = 0, self.n
+        bad, info = self.f.numeric_phase(0, beta)
+        if self._agree(bad, info) >= 0:
+            return self.status
+        if self.world > 1 and self.tensors:
+            self.allreduce(self.tensors)
+        bad, info = self.f.numeric_phase(1, beta)
+        self._agree(bad, info)
+        return self.status

@@ -24,13 +24,15 @@ struct Emu {
 };
 
 void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t *Ap, const int64_t *Ai,
-         const double *Ax, double beta, double *Lx, std::vector<double> &Dinv, std::vector<int> &info)
+         const double *Ax, double beta, double *Lx, std::vector<double> &Dinv, std::vector<int> &info,
+         const int8_t *asm_mask = nullptr, bool init = true)
 {
-    std::fill(Lx, Lx + S.xsize, 0.0);
+    if (init) std::fill(Lx, Lx + S.xsize, 0.0);
     info.assign(S.nsuper + 2, 0);
     Dinv.assign(sc.dinv_size + 1, 0.0);
-    for (int64_t k = 0; k < ncols_asm; k++) {
+    for (int64_t k = 0; init && k < ncols_asm; k++) {
         int s = sc.supermap[k];
+        if (asm_mask && !asm_mask[s]) continue;
         int64_t k1 = S.Super[s], psi = S.Lpi[s], psx = S.Lpx[s], nsrow = S.Lpi[s + 1] - psi;
         int64_t base = psx + (k - k1) * nsrow;
         for (int64_t p = Ap[k]; p < Ap[k + 1]; p++) {
@@ -135,6 +137,23 @@ int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int
     } else if (Dinv_out) {
         std::copy(Dinv.begin(), Dinv.begin() + sc.dinv_size, Dinv_out);
     }
+    return 0;
+}
+
+// one multi-GPU phase (mi355_factor_numeric_phase): masked schedule, optional init/assembly
+int emu_numeric_phase(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                      const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                      const double *Ax, double beta, const int8_t *proc_mask, const int8_t *asm_mask, int init,
+                      double *Lx, int64_t *first_bad, int64_t *info_out)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc, proc_mask);
+    std::vector<double> Dinv; std::vector<int> info;
+    run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info, asm_mask, init != 0);
+    if (info[nsuper + 1] != 0) return -10;
+    *first_bad = -1; *info_out = 0;
+    for (int64_t s = 0; s < nsuper; s++) if (info[s]) { *first_bad = s; *info_out = info[s]; break; }
     return 0;
 }
 

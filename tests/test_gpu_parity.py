@@ -200,3 +200,37 @@ def test_empty_factor(engine):
     L = engine.SupernodalFactor(sym)
     assert L.super_numeric(np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0)) == 0
     assert L.minor == 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multigpu_phases_simulated_on_one_gpu(engine, world):
+    """the two-phase multi-GPU path (mi355_factor_set_partition / _numeric_phase) with `world` handles on
+    one GPU and the top-panel reduction done by hand on the device views RCCL would reduce"""
+    import torch
+    from oracle import port
+    from suitesparse_amd import multigpu
+    from test_multigpu import problem
+    g = problem("lap3d", 16)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    facs = []
+    for r in range(world):
+        L = engine.SupernodalFactor(g)
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        facs.append(multigpu.PartitionedFactor(L, g, r, world, allreduce=lambda t: None))
+    for f in facs:
+        assert f.f.numeric_phase(0) == (-1, 0)
+    torch.cuda.synchronize()
+    for k in range(len(facs[0].tensors)):
+        tot = sum(f.tensors[k] for f in facs)
+        for f in facs:
+            f.tensors[k].copy_(tot)
+    torch.cuda.synchronize()
+    for f in facs:
+        assert f.f.numeric_phase(1) == (-1, 0)
+    owner = facs[0].part["owner"]
+    for r, f in enumerate(facs):
+        Lx = f.f.Lx()
+        for s in range(g["nsuper"]):
+            if owner[s] in (r, -1):
+                a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                assert relerr(Lx[a:b], Lo[a:b]) < TOL_L

@@ -1,0 +1,165 @@
+"""CPU tests of the multi-GPU host logic (suitesparse_amd/multigpu.py): the subtree partition,
+the two-phase schedule and the top-panel reduction, executed with the CPU schedule emulator --
+sequentially for 1..8 simulated ranks, and for real with torch.distributed (gloo, world_size 2)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, sym_of, relerr
+from suitesparse_amd import multigpu
+
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+
+
+class EmuFactor:
+    """same interface as engine.SupernodalFactor's multi-GPU part, on the CPU emulator"""
+
+    def __init__(self, g):
+        self.g = g
+        self.E = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+        self.E.emu_numeric_phase.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
+                                             i64p, i64p, f64p, C.c_double, i8p, i8p, C.c_int, f64p,
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self.Lx = np.zeros(g["xsize"])
+
+    def set_partition(self, local, top, asm):
+        self.local, self.top, self.asm = (np.ascontiguousarray(m, dtype=np.int8) for m in (local, top, asm))
+
+    def numeric_phase(self, phase, beta=0.0):
+        g = self.g
+        bad, info = C.c_int64(-1), C.c_int64(0)
+        rc = self.E.emu_numeric_phase(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"],
+                                      g["xsize"], g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64),
+                                      beta, self.local if phase == 0 else self.top, self.asm, int(phase == 0),
+                                      self.Lx, C.byref(bad), C.byref(info))
+        assert rc == 0
+        return int(bad.value), int(info.value)
+
+    def top_tensors(self, ranges):
+        import torch
+        t = torch.from_numpy(self.Lx)
+        return [t[lo:hi] for lo, hi in ranges]
+
+
+def problem(kind="lap3d", size=12):
+    from suitesparse_amd import problems, symbolic
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "elast": problems.elasticity27}[kind](size)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    g = dict(sym, Sp=Sp, Si=Si, Sx=Sx, beta=0.0)
+    g["ssize"] = len(sym["Ls"])
+    return g
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_partition_is_a_partition(world):
+    g = problem("lap3d", 14)
+    part = multigpu.partition(g, world)
+    owner = part["owner"]
+    parent, work = multigpu.supernode_tree(g)
+    assert owner.shape == (g["nsuper"],) and owner.max() < world
+    # top is closed under "parent": an owned supernode's ancestors are owned by the same rank or top
+    for s in range(g["nsuper"]):
+        p = parent[s]
+        if p >= 0:
+            assert owner[p] == -1 or owner[p] == owner[s]
+            if owner[s] == -1:
+                assert owner[p] == -1
+    assert abs(part["top_work"] + sum(part["rank_work"]) - part["total_work"]) <= 1e-6 * part["total_work"]
+    if world > 1:
+        assert max(part["rank_work"]) <= 0.75 * part["total_work"]
+        for lo, hi in part["top_ranges"]:
+            assert 0 <= lo < hi <= g["xsize"]
+
+
+@pytest.mark.parametrize("kind,size,world", [("lap3d", 12, 2), ("lap3d", 12, 4), ("lap2d", 40, 8), ("elast", 5, 3)])
+def test_phases_with_simulated_ranks_match_oracle(kind, size, world):
+    from oracle import port
+    g = problem(kind, size)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert so == 0
+    facs = [EmuFactor(g) for _ in range(world)]
+
+    class Shared:            # the all-reduce of the simulated ranks: sum over all copies, once
+        done = False
+
+    runners = []
+
+    def allreduce_factory(r):
+        def ar(tensors):
+            pass             # replaced below: the sum needs every rank's phase 0 first
+        return ar
+    runners = [multigpu.PartitionedFactor(f, g, r, world, allreduce=allreduce_factory(r)) for r, f in enumerate(facs)]
+    # phase 0 everywhere
+    for rn in runners:
+        assert rn.f.numeric_phase(0) == (-1, 0)
+    # reduction
+    ranges = runners[0].part["top_ranges"]
+    for lo, hi in ranges:
+        tot = sum(f.Lx[lo:hi] for f in facs)
+        for f in facs:
+            f.Lx[lo:hi] = tot
+    # phase 1 everywhere
+    for rn in runners:
+        assert rn.f.numeric_phase(1) == (-1, 0)
+    owner = runners[0].part["owner"]
+    Lpx = g["Lpx"]
+    for r, f in enumerate(facs):
+        for s in range(g["nsuper"]):
+            if owner[s] == r or owner[s] == -1:
+                a, b = int(Lpx[s]), int(Lpx[s + 1])
+                assert relerr(f.Lx[a:b], Lo[a:b]) < 1e-11, (r, s)
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+import test_multigpu as tm
+from suitesparse_amd import multigpu
+from oracle import port
+g = tm.problem("lap3d", 10)
+f = tm.EmuFactor(g)
+run = multigpu.PartitionedFactor(f, g, rank, world)
+st = run.numeric()
+so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+owner = run.part["owner"]
+worst = 0.0
+for s in range(g["nsuper"]):
+    if owner[s] in (rank, -1):
+        a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+        worst = max(worst, float(np.abs(f.Lx[a:b] - Lo[a:b]).max() / np.abs(Lo).max()))
+# not positive definite: every rank must agree on status and minor
+g2 = dict(g); Sx = g["Sx"].copy(); col = int(g["n"] // 2); Sx[g["Sp"][col]] = -5.0; g2["Sx"] = Sx
+f2 = tm.EmuFactor(g2)
+run2 = multigpu.PartitionedFactor(f2, g2, rank, world)
+st2 = run2.numeric()
+so2, mo2, _ = port.super_numeric(g2, g2["Sp"], g2["Si"], g2["Sx"])
+print("RESULT", rank, st, worst, st2, run2.minor, so2, mo2, flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_run(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(lines) == 2
+    for l in lines:
+        st, worst, st2, minor2, so2, mo2 = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7])
+        assert st == 0 and worst < 1e-11
+        assert st2 == so2 == 1 and minor2 == mo2
