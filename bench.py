@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--solve", action="store_true", help="also time the supernodal solve (nrhs 1)")
+    ap.add_argument("--tune", default="", help="experiments: key=value,... (0 big_min_m, 1 big_min_n, 2 outer block)")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +102,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl")
     from suitesparse_amd import engine
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        engine.set_tuning(int(k), int(v))
 
     default_grid = {"lap3d": 150, "lap2d": 2000, "elast": 80}[args.problem]
     grid = args.grid or default_grid
@@ -169,6 +173,7 @@ def main():
         "config": {"workload": name + ", geometric nested dissection, supernodal LL' (int64, double)",
                    "n": p["n"], "fl": sym["fl"], "lnz": sym["lnz"], "nsuper": sym["nsuper"],
                    "xsize": sym["xsize"], "levels": int(st["nlevels"]), "update_pairs": int(st["npairs"]),
+                   "exec_flops": {"update": st["flops_update"], "panel": st["flops_panel"]},
                    "parallelism": "1 GPU" if world == 1 else f"subtree-to-GPU x{world} + replicated top",
                    "analyze_s": round(t_analyze, 2), "setup_s": round(t_setup, 2),
                    "frac_fp64_mfma_peak": round(gflops * 1e-3 / (FP64_MFMA_PEAK_TFLOPS * world), 4),

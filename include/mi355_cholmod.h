@@ -142,9 +142,19 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *            15 reserved */
 int mi355_factor_get_stats(mi355_factor *handle, double *out16);
 
-/* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device`, in TFLOP/s (no counterpart
- * in the reference; used by bench.py to state the FP64 matrix peak next to the vendor figure). */
-int mi355_debug_mfma_f64_rate(int device, double *tflops);
+/* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device` (no counterpart in the reference;
+ * used by bench.py to state the FP64 matrix peak next to the vendor figure).
+ * out3[0] TFLOP/s chip-wide, out3[1] shader cycles per MFMA seen by one wave (2 waves per SIMD),
+ * out3[2] shader clock in MHz during the loop. */
+int mi355_debug_mfma_f64_rate(int device, double *out3);
+
+/* Rate of ONE trailing-update task (lower trapezoid M x N, depth K) on random data with kernel 0
+ * (k_gemm64) or 1 (k_gemm128); kernel micro-benchmark for profiles/, no reference counterpart. */
+int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters, double *tflops);
+
+/* key 0: minimum M, key 1: minimum N of a task routed to the 128x128-tile kernel (affects
+ * factors created afterwards). */
+int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

@@ -215,8 +215,12 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
             tm.begin(0);
-            hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
-                               D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+            if (st.big)
+                hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+            else
+                hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
             tm.end(0);
             F->st_ngemm += 1;
             F->st_tiles += (double)st.ntiles;
@@ -619,6 +623,7 @@ __global__ __launch_bounds__(256) void k_mfma_rate(int iters, double *out)
 {
     v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
         a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
@@ -627,6 +632,63 @@ __global__ __launch_bounds__(256) void k_mfma_rate(int iters, double *out)
     }
     v4d s = a0 + a1 + a2 + a3;
     if (s[0] + s[1] + s[2] + s[3] == 123.456) out[0] = s[0];
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[1] = (double)(c1 - c0) / (4.0 * iters);                 // shader cycles per MFMA (this wave)
+        out[2] = (double)(c1 - c0) / (double)(r1 - r0) * 100.0;     // shader clock in MHz (realtime = 100 MHz)
+    }
+}
+
+int mi355_set_tuning(int key, int value)
+{
+    if (key == 0) tuning().big_min_m = value;
+    else if (key == 1) tuning().big_min_n = value;
+    else if (key == 2) tuning().ob = value;
+    else return fail(MI355_INVALID, "unknown tuning key");
+    return MI355_OK;
+}
+
+// one GEMM_DIRECT_SUB task C(MxN lower trapezoid) -= A(MxK) A(0:N,:)^T on random data, `iters` launches;
+// kernel: 0 = k_gemm64, 1 = k_gemm128.  Reports TFLOP/s of the useful (lower-trapezoid) flops.
+int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters, double *tflops)
+{
+    g_err.clear();
+    if (!tflops || M < N || N <= 0 || K <= 0 || iters <= 0) return fail(MI355_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t lda = M;
+    std::vector<double> hA((size_t)lda * K);
+    uint64_t x = 88172645463325252ull;
+    for (auto &v : hA) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) / 9007199254740992.0 - 0.5; }
+    DevBuf<double> buf;
+    HIP_TRY(buf.alloc((size_t)lda * K + (size_t)M * N));
+    HIP_TRY(hipMemcpy(buf.p, hA.data(), hA.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(buf.p + (size_t)lda * K, 0, (size_t)M * N * sizeof(double)));
+    GemmTask t;
+    t.a_off = 0; t.b_off = 0; t.c_off = (int64_t)lda * K; t.rm_off = -1;
+    t.lda = (int32_t)lda; t.ldb = (int32_t)lda; t.ldc = M; t.M = M; t.N = N; t.K = K;
+    t.mode = GEMM_DIRECT_SUB; t.big = kernel; t.tile0 = 0;
+    DevBuf<GemmTask> dt;
+    HIP_TRY(dt.upload(&t, 1, 0));
+    const int64_t ntiles = gemm_tiles(M, N, t.mode, kernel ? BTILE : TILE);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int it = -2; it < iters; it++) {
+        if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
+        if (kernel)
+            hipLaunchKernelGGL(k_gemm128, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, 1, buf.p, buf.p, (const int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, 1, buf.p, buf.p, (const int32_t *)nullptr);
+    }
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double flops = 2.0 * K * ((double)N * (N + 1) / 2 + (double)(M - N) * N) * iters;
+    *tflops = flops / (ms * 1e-3) * 1e-12;
+    return MI355_OK;
 }
 
 int mi355_debug_mfma_f64_rate(int device, double *tflops)
@@ -637,7 +699,7 @@ int mi355_debug_mfma_f64_rate(int device, double *tflops)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     DevBuf<double> d;
-    HIP_TRY(d.alloc(1));
+    HIP_TRY(d.alloc(8));
     const int iters = 20000, grid = prop.multiProcessorCount * 2;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -652,6 +714,10 @@ int mi355_debug_mfma_f64_rate(int device, double *tflops)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     const double flops = (double)grid * 4 /*waves*/ * iters * 4.0 /*mfma per iter*/ * 2048.0;
     *tflops = flops / (ms * 1e-3) * 1e-12;
+    double h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+    tflops[1] = h[1];
+    tflops[2] = h[2];
     return MI355_OK;
 }
 

@@ -221,6 +221,140 @@ __global__ __launch_bounds__(256) void k_gemm64(
 }
 
 //------------------------------------------------------------------------------
+// k_gemm128: the large-task variant.  128x128 tile per 256-thread workgroup, 4 waves as
+// 2x2, each wave 64x64 = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs), K staged 16
+// at a time through a DOUBLE-BUFFERED LDS image: the global loads of stage k+1 are issued
+// into registers before the 64 MFMAs of stage k and written to the other buffer after
+// them, one barrier per stage.  Same operand-role swap and epilogues as k_gemm64.
+//------------------------------------------------------------------------------
+constexpr int G128_KS = 16;
+constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row => conflict-free ds_read_b64
+
+__global__ __launch_bounds__(256, 2) void k_gemm128(
+    const GemmTask *__restrict__ tasks, int ntasks, double *__restrict__ Lx,
+    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
+{
+    __shared__ double As[2][G128_KS][G128_LD];
+    __shared__ double Bs[2][G128_KS][G128_LD];
+    __shared__ int rmM[BTILE], rmN[BTILE];
+
+    const int tid = threadIdx.x;
+    const int64_t bid = blockIdx.x;
+    int lo = 0, hi = ntasks - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const GemmTask t = tasks[lo];
+    const int M = t.M, N = t.N, K = t.K, mode = t.mode;
+    const int MT = (M + BTILE - 1) / BTILE, NT = (N + BTILE - 1) / BTILE;
+    int tm, tn;
+    tile_coords(bid - t.tile0, MT, NT, mode, tm, tn);
+    if (tm >= MT || tn >= NT) return;
+    const int m0 = tm * BTILE, n0 = tn * BTILE;
+
+    const double *__restrict__ A = Lx + t.a_off;
+    const double *__restrict__ B = (mode == GEMM_OVERWRITE ? Dinv : Lx) + t.b_off;
+    const int64_t lda = t.lda, ldb = t.ldb;
+
+    if (mode == GEMM_SCATTER_SUB) {
+        if (tid < BTILE) rmM[tid] = (m0 + tid < M) ? relmap[t.rm_off + m0 + tid] : 0;
+        else { int j = tid - BTILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // a diagonal tile of a lower-trapezoid task needs nothing from its strictly upper 64x64 quadrant
+    const bool skip_mma = (mode != GEMM_OVERWRITE) && (m0 == n0) && (wm < wn);
+
+    v4d acc[4][4];                               // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int lrow = tid & 127, lk = tid >> 7;   // each thread stages 8 k-values of one A row and one B row
+    const bool arow_ok = (m0 + lrow) < M, brow_ok = (n0 + lrow) < N;
+    const double *Ap = A + (m0 + lrow);
+    const double *Bp = B + (n0 + lrow);
+    double ra[8], rb[8];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int kk = k0 + lk + 2 * q;
+            const bool kok = kk < K;
+            ra[q] = (arow_ok && kok) ? Ap[(int64_t)kk * lda] : 0.0;
+            rb[q] = (brow_ok && kok) ? Bp[(int64_t)kk * ldb] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            As[buf][lk + 2 * q][lrow] = ra[q];
+            Bs[buf][lk + 2 * q][lrow] = rb[q];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += G128_KS) {
+        const bool more = (k0 + G128_KS) < K;
+        if (more) gload(k0 + G128_KS);
+        if (!skip_mma) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int kk = ks * 4 + l4;
+                double a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
+                    b[i] = Bs[buf][kk][wn * 64 + i * 16 + l15];
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (skip_mma) return;
+
+    const int64_t ldc = t.ldc;
+    double *__restrict__ C = Lx + t.c_off;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const int ml = wm * 64 + mi * 16 + l15;
+            const int m = m0 + ml;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nl = wn * 64 + ni * 16 + l4 + 4 * r;
+                const int n = n0 + nl;
+                if (m < M && n < N) {
+                    const double v = acc[ni][mi][r];
+                    if (mode == GEMM_SCATTER_SUB) {
+                        if (m >= n) atomic_add_f64(C + rmM[ml] + (int64_t)rmN[nl] * ldc, -v);
+                    } else if (mode == GEMM_DIRECT_SUB) {
+                        if (m >= n) C[m + (int64_t)n * ldc] -= v;
+                    } else {
+                        C[m + (int64_t)n * ldc] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
 // k_potrf64: lower Cholesky of one nb x nb (nb <= 64) diagonal block, in LDS, plus
 // its inverse (used as the TRSM operand and by the solves).  One workgroup per task.
 // info[s] receives the 1-based column (inside s) of the first pivot that is <= 0 or

@@ -5,6 +5,12 @@
 
 namespace mi355 {
 
+Tuning &tuning()
+{
+    static Tuning t;
+    return t;
+}
+
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile)
 {
     if (M <= 0 || N <= 0) return 0;
@@ -74,22 +80,30 @@ GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int
     return t;
 }
 
-// append one GEMM step; assigns tile0 prefix sums; splits nothing
+// append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
+// kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
+// tile0 prefix sums
 void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level)
 {
     if (tasks.empty()) return;
-    Step st;
-    st.kind = STEP_GEMM; st.level = level; st.big = 0; st.pad = 0;
-    st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
-    for (auto &t : tasks) {
-        int64_t nt = gemm_tiles(t.M, t.N, t.mode, TILE);
-        if (nt == 0) continue;
-        t.tile0 = st.ntiles;
-        st.ntiles += nt;
-        out.gemm.push_back(t);
-        st.count++;
+    const Tuning &tu = tuning();
+    for (int big = 1; big >= 0; big--) {
+        Step st;
+        st.kind = STEP_GEMM; st.level = level; st.big = big; st.pad = 0;
+        st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
+        for (auto &t : tasks) {
+            const int is_big = (t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
+            if (is_big != big) continue;
+            int64_t nt = gemm_tiles(t.M, t.N, t.mode, big ? BTILE : TILE);
+            if (nt == 0) continue;
+            t.big = big;
+            t.tile0 = st.ntiles;
+            st.ntiles += nt;
+            out.gemm.push_back(t);
+            st.count++;
+        }
+        if (st.count > 0) out.steps.push_back(st);
     }
-    if (st.count > 0) out.steps.push_back(st);
 }
 
 }  // namespace
@@ -141,8 +155,9 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
 
         // ---- panel: blocked partial Cholesky of the nsrow x ncol_eff panel (a3.9 + a3.10)
         size_t it = 0;
-        for (int64_t J = 0; J < ncol_eff; J += OB) {
-            const int64_t Jend = std::min<int64_t>(J + OB, ncol_eff);
+        const int64_t ob = std::max(NB, (tuning().ob / NB) * NB);
+        for (int64_t J = 0; J < ncol_eff; J += ob) {
+            const int64_t Jend = std::min<int64_t>(J + ob, ncol_eff);
             for (int64_t j = J; j < Jend; j += NB, it++) {
                 const int64_t nb = std::min<int64_t>(NB, Jend - j);
                 const int64_t below = nsrow - (j + nb);
@@ -168,7 +183,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                             psx + (j + nb) + j * nsrow, psx + (j + nb) + j * nsrow,
                             psx + (j + nb) + (j + nb) * nsrow, -1, nsrow, nsrow, nsrow,
                             below, ninner, nb, GEMM_DIRECT_SUB));
-                        out.flops_panel += 2.0 * below * ninner * nb;
+                        out.flops_panel += ((double)ninner * ninner + 2.0 * (double)(below - ninner) * ninner) * nb;
                     }
                     if (j + nb == Jend && Jend < ncol_eff) {
                         const int64_t K = Jend - J;
@@ -176,7 +191,8 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                             psx + Jend + J * nsrow, psx + Jend + J * nsrow,
                             psx + Jend + Jend * nsrow, -1, nsrow, nsrow, nsrow,
                             nsrow - Jend, ncol_eff - Jend, K, GEMM_DIRECT_SUB));
-                        out.flops_panel += 2.0 * (double)(nsrow - Jend) * (ncol_eff - Jend) * K;
+                        { const double Nn = (double)(ncol_eff - Jend), Mm = (double)(nsrow - Jend);
+                          out.flops_panel += (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * K; }
                     }
                 }
             }

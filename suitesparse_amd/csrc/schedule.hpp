@@ -22,7 +22,7 @@
 namespace mi355 {
 
 constexpr int NB = 64;        // diagonal-block / panel width of the device POTRF
-constexpr int OB = 256;       // outer block (trailing updates with K = OB)
+constexpr int OB = 512;       // outer block (trailing updates with K = OB); 512 measured best at 150^3
 constexpr int TILE = 64;      // GEMM output tile (TILE x TILE per workgroup), small-tile kernel
 constexpr int BTILE = 128;    // big-tile kernel
 constexpr int SOLVE_ROWS = 256;  // rows of L per workgroup in the solve update kernels
@@ -117,6 +117,10 @@ std::string validate_symbolic(const Symbolic &S);
 // and push their updates -- the multi-GPU phases (own subtrees / shared top) of SURVEY 8(e).
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
                     const int8_t *mask = nullptr);
+
+// tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; };
+Tuning &tuning();
 
 // number of TILE-tiles of one task
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile);

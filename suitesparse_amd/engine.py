@@ -34,6 +34,7 @@ EXPORTS = [
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
+    "mi355_debug_gemm_rate", "mi355_set_tuning",
 ]
 
 _LIB = None
@@ -91,10 +92,28 @@ def probe():
 
 def mfma_f64_rate(device=0):
     """measured TFLOP/s of bare v_mfma_f64_16x16x4_f64 issue on `device`"""
+    return mfma_f64_probe(device)[0]
+
+
+def mfma_f64_probe(device=0):
+    """(TFLOP/s, shader cycles per MFMA for one of 2 waves on a SIMD, shader clock MHz)"""
+    out = np.zeros(3)
+    lib().mi355_debug_mfma_f64_rate.argtypes = [C.c_int, _f64p]
+    _check(lib().mi355_debug_mfma_f64_rate(int(device), out))
+    return tuple(out.tolist())
+
+
+def gemm_rate(kernel, M, N, K, iters=10, device=0):
+    """TFLOP/s of one lower-trapezoid trailing-update task on kernel 0 (64x64 tile) / 1 (128x128)"""
     out = C.c_double(0.0)
-    lib().mi355_debug_mfma_f64_rate.argtypes = [C.c_int, C.POINTER(C.c_double)]
-    _check(lib().mi355_debug_mfma_f64_rate(int(device), C.byref(out)))
+    f = lib().mi355_debug_gemm_rate
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    _check(f(int(device), int(kernel), int(M), int(N), int(K), int(iters), C.byref(out)))
     return out.value
+
+
+def set_tuning(key, value):
+    _check(lib().mi355_set_tuning(int(key), int(value)))
 
 
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",

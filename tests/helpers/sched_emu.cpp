@@ -77,7 +77,8 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const GemmTask &t = sc.gemm[ti];
                 if (t.tile0 != tiles) { info[S.nsuper + 1] = -1; }       // prefix sums must be exact
-                tiles += gemm_tiles(t.M, t.N, t.mode, TILE);
+                tiles += gemm_tiles(t.M, t.N, t.mode, t.big ? BTILE : TILE);
+                if (t.big != st.big) info[S.nsuper + 1] = -1;
                 const double *A = Lx + t.a_off;
                 const double *B = (t.mode == GEMM_OVERWRITE ? Dinv.data() : Lx) + t.b_off;
                 C.assign((size_t)t.M * t.N, 0.0);
