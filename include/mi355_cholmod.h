@@ -56,7 +56,8 @@ const char *mi355_last_error(void);
  * Super/Lpi/Lpx/Ls, replays the descendant lists into the level schedule, builds
  * all relative maps on the device, allocates Lx (xsize entries) in HBM.
  * Arrays are cholmod_factor's super/pi/px/s (cholmod.h:1604-1651); they are copied.
- * xtype: MI355_REAL (complex factors: MI355_NOT_INSTALLED until the cd_ kernels land).
+ * xtype: the xtype of L -- MI355_REAL, or MI355_COMPLEX (interleaved re,im; also what a
+ * zomplex A produces, cholmod_super_numeric.c:223-225).
  * replaces gpu_init + cholmod_l_gpu_allocate (CHOLMOD/GPU/t_cholmod_gpu.c:84-160,
  * cholmod_gpu.c:426-543) and the per-supernode Map/RelativeMap kernels. */
 int mi355_factor_create(int xtype, int64_t n, int64_t nsuper,
@@ -71,9 +72,15 @@ int mi355_factor_free(mi355_factor *handle);
  *      (CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:133-1279) */
 
 /* Stage the matrix S = tril(P A P') (stype < 0; cholmod_sparse p/i/nz/x, packed when
- * Anz == NULL) in HBM.  Host pointers; copied. */
+ * Anz == NULL) in HBM.  Host pointers; copied.  Ax holds E doubles per entry (E = 2,
+ * interleaved, for a complex L). */
 int mi355_factor_set_matrix(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
                             const int64_t *Anz, const double *Ax);
+
+/* zomplex A (cholmod_sparse x and z arrays) for a complex L: interleaved on the way in, as the
+ * zd_ worker does (t_cholmod_super_numeric_worker.c:69-83). */
+int mi355_factor_set_matrix_zomplex(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
+                                    const int64_t *Anz, const double *Ax, const double *Az);
 
 /* Factorize the staged matrix: Lx (device) <- chol(S + beta*I).  *status receives
  * CHOLMOD_OK or CHOLMOD_NOT_POSDEF and *minor the reference's L->minor (n if positive
@@ -82,7 +89,7 @@ int mi355_factor_set_matrix(mi355_factor *handle, const int64_t *Ap, const int64
 int mi355_factor_numeric(mi355_factor *handle, double beta_re,
                          int quick_return_if_not_posdef, int64_t *minor, int *status);
 
-/* Copy the numeric factor to the host array L->x (xsize doubles). */
+/* Copy the numeric factor to the host array L->x (E*xsize doubles). */
 int mi355_factor_get_Lx(mi355_factor *handle, double *Lx);
 
 /* One call = cholmod_super_numeric's numeric part for (int64, double, real, stype<0):
@@ -111,7 +118,8 @@ int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,
 /* ---- supernodal triangular solves: replace cholmod_l_super_lsolve / _ltsolve
  *      (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153; workers
  *      t_cholmod_super_solve_worker.c:20-303,309-580).  X is n x nrhs, column-major,
- *      leading dimension d >= n, host memory, overwritten with L\X or L'\X.
+ *      leading dimension d >= n (in entries; E doubles per entry, the xtype of L), host
+ *      memory, overwritten with L\X or L^H\X.
  *      No workspace E is needed. */
 int mi355_super_lsolve(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);
 int mi355_super_ltsolve(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);

@@ -19,6 +19,7 @@
 #include "schedule.hpp"
 #include "kernels.hip.hpp"
 #include "solve_kernels.hip.hpp"
+#include "kernels_complex.hip.hpp"
 
 using namespace mi355;
 
@@ -79,6 +80,7 @@ struct mi355_factor_s {
     int device = 0;
     hipStream_t stream = nullptr;
     int xtype = MI355_REAL;
+    int E = 1;                  // doubles per entry: 1 real, 2 complex (interleaved)
     // host copy of the symbolic factor
     std::vector<int64_t> Super, Lpi, Lpx, Ls;
     Symbolic sym;
@@ -191,13 +193,14 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     const Symbolic &S = F->sym;
     tm.begin(2);
     if (init) {
-        HIP_TRY(hipMemsetAsync(F->Lx.p, 0, (size_t)S.xsize * sizeof(double), F->stream));
+        HIP_TRY(hipMemsetAsync(F->Lx.p, 0, (size_t)S.xsize * F->E * sizeof(double), F->stream));
         HIP_TRY(hipMemsetAsync(F->info.p, 0, (size_t)(S.nsuper + 2) * sizeof(int), F->stream));
     }
+    const bool cplx = F->E == 2;
     if (init && ncols_asm > 0) {
         const unsigned grid = (unsigned)((ncols_asm + 255) / 256);
-        hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm, F->Ap.p, F->Ai.p,
-                           F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
+        hipLaunchKernelGGL(cplx ? k_assemble_c : k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
+                           F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
                            F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta, smask);
         HIP_TRY(hipGetLastError());
     }
@@ -207,7 +210,7 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
         if (st.kind == STEP_POTRF) {
             if (st.count > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many POTRF tasks in one step");
             tm.begin(1);
-            hipLaunchKernelGGL(k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+            hipLaunchKernelGGL(cplx ? k_potrf64c : k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
                                D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p);
             tm.end(1);
             F->st_npotrf += 1;
@@ -215,7 +218,10 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
             tm.begin(0);
-            if (st.big)
+            if (cplx)
+                hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+            else if (st.big)
                 hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
             else
@@ -262,8 +268,8 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     g_err.clear();
     if (!handle) return fail(MI355_INVALID, "null handle pointer");
     *handle = nullptr;
-    if (xtype != MI355_REAL)
-        return fail(MI355_NOT_INSTALLED, "only real double factors are handled on the device so far");
+    if (xtype != MI355_REAL && xtype != MI355_COMPLEX)
+        return fail(MI355_INVALID, "factor xtype must be MI355_REAL or MI355_COMPLEX (a zomplex A gives a complex L)");
     if (n < 0 || nsuper < 0 || ssize < 0 || xsize < 0) return fail(MI355_INVALID, "negative size");
     if (nsuper > 0 && (!Super || !Lpi || !Lpx || !Ls)) return fail(MI355_INVALID, "null symbolic array");
     int ndev = 0;
@@ -276,6 +282,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     struct Guard { mi355_factor_s *f; ~Guard() { if (f) mi355_factor_free(f); } } guard{F};
     F->device = device;
     F->xtype = xtype;
+    F->E = (xtype == MI355_COMPLEX) ? 2 : 1;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
 
@@ -291,6 +298,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     const std::string bad = validate_symbolic(F->sym);
     if (!bad.empty()) return fail(MI355_INVALID, "invalid supernodal symbolic factor: " + bad);
 
+    F->sym.no_big = (F->E == 2);        // the complex path has the 64x64-tile kernel only
     build_schedule(F->sym, nsuper, 0, F->full.sched);
 
     // device copies of the symbolic arrays (row indices narrowed to int32)
@@ -301,8 +309,8 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     HIP_TRY(F->dSuper.upload(F->Super.data(), F->Super.size(), F->stream));
     HIP_TRY(F->dLpi.upload(F->Lpi.data(), F->Lpi.size(), F->stream));
     HIP_TRY(F->dLpx.upload(F->Lpx.data(), F->Lpx.size(), F->stream));
-    HIP_TRY(F->Lx.alloc((size_t)xsize));
-    HIP_TRY(F->Dinv.alloc((size_t)F->full.sched.dinv_size));
+    HIP_TRY(F->Lx.alloc((size_t)xsize * F->E));
+    HIP_TRY(F->Dinv.alloc((size_t)F->full.sched.dinv_size * F->E));
     HIP_TRY(F->info.alloc((size_t)nsuper + 2));
     int rc = upload_schedule(F, F->full);
     if (rc != MI355_OK) return rc;
@@ -323,8 +331,8 @@ int mi355_factor_free(mi355_factor *F)
     return MI355_OK;
 }
 
-int mi355_factor_set_matrix(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
-                            const int64_t *Anz, const double *Ax)
+static int set_matrix_impl(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
+                           const int64_t *Anz, const double *Ax, const double *Az)
 {
     g_err.clear();
     int rc = check_handle(F);
@@ -345,11 +353,32 @@ int mi355_factor_set_matrix(mi355_factor *F, const int64_t *Ap, const int64_t *A
         if (Ai[p] < 0 || Ai[p] >= n) return fail(MI355_INVALID, "matrix row index out of range");
     HIP_TRY(F->Ap.upload(Ap, (size_t)n + 1, F->stream));
     HIP_TRY(F->Ai.upload(Ai, (size_t)nzmax, F->stream));
-    HIP_TRY(F->Ax.upload(Ax, (size_t)nzmax, F->stream));
+    if (F->E == 2 && Az) {
+        // zomplex A: interleave, as the zd_ worker does on the fly (worker :69-83)
+        std::vector<double> z((size_t)nzmax * 2);
+        for (int64_t p = 0; p < nzmax; p++) { z[2 * p] = Ax[p]; z[2 * p + 1] = Az[p]; }
+        HIP_TRY(F->Ax.upload(z.data(), z.size(), F->stream));
+    } else {
+        if (F->E == 1 && Az) return fail(MI355_INVALID, "complex type mismatch: zomplex A with a real L");
+        HIP_TRY(F->Ax.upload(Ax, (size_t)nzmax * F->E, F->stream));
+    }
     F->A_unpacked = (Anz != nullptr);
     if (Anz) HIP_TRY(F->Anz.upload(Anz, (size_t)n, F->stream));
     F->have_A = true;
     return MI355_OK;
+}
+
+int mi355_factor_set_matrix(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
+                            const int64_t *Anz, const double *Ax)
+{
+    return set_matrix_impl(F, Ap, Ai, Anz, Ax, nullptr);
+}
+
+int mi355_factor_set_matrix_zomplex(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
+                                    const int64_t *Anz, const double *Ax, const double *Az)
+{
+    if (!Az) return fail(MI355_INVALID, "null Az");
+    return set_matrix_impl(F, Ap, Ai, Anz, Ax, Az);
 }
 
 int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_not_posdef,
@@ -409,7 +438,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
         const int64_t nsrow = S.Lpi[sf + 1] - S.Lpi[sf];
         const int64_t tail = S.Lpx[sf] + nsrow * nscol2;
         if (tail < S.xsize)
-            HIP_TRY(hipMemsetAsync(F->Lx.p + tail, 0, (size_t)(S.xsize - tail) * sizeof(double), F->stream));
+            HIP_TRY(hipMemsetAsync(F->Lx.p + tail * F->E, 0, (size_t)(S.xsize - tail) * F->E * sizeof(double), F->stream));
         HIP_TRY(hipStreamSynchronize(F->stream));
     }
     HIP_TRY(hipEventRecord(e1, F->stream));
@@ -433,7 +462,7 @@ int mi355_factor_get_Lx(mi355_factor *F, double *Lx)
     if (rc) return rc;
     if (!Lx) return fail(MI355_INVALID, "null Lx");
     if (F->sym.xsize > 0) {
-        HIP_TRY(hipMemcpyAsync(Lx, F->Lx.p, (size_t)F->sym.xsize * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+        HIP_TRY(hipMemcpyAsync(Lx, F->Lx.p, (size_t)F->sym.xsize * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
         HIP_TRY(hipStreamSynchronize(F->stream));
     }
     return MI355_OK;
@@ -536,14 +565,16 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, F->stream));
     const int nr = (int)nrhs;
+    const bool cplx = F->E == 2;
     if (lower) {
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
-            hipLaunchKernelGGL(k_solve_diag<false>, dim3((unsigned)st.count), dim3(256), 0, F->stream,
-                               P + st.first, F->Dinv.p, X, d, nr);
+            hipLaunchKernelGGL(cplx ? k_solve_diag_c<false> : k_solve_diag<false>, dim3((unsigned)st.count), dim3(256),
+                               0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             if (st.stiles > 0)
-                hipLaunchKernelGGL(k_solve_fwd_update, dim3((unsigned)st.stiles), dim3(SOLVE_ROWS), 0, F->stream,
+                hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
+                                   dim3(SOLVE_ROWS), 0, F->stream,
                                    P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
             HIP_TRY(hipGetLastError());
         }
@@ -552,10 +583,11 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
             if (st.stiles > 0)
-                hipLaunchKernelGGL(k_solve_bwd_update, dim3((unsigned)st.stiles), dim3(SOLVE_ROWS), 0, F->stream,
+                hipLaunchKernelGGL(cplx ? k_solve_bwd_update_c : k_solve_bwd_update, dim3((unsigned)st.stiles),
+                                   dim3(SOLVE_ROWS), 0, F->stream,
                                    P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
-            hipLaunchKernelGGL(k_solve_diag<true>, dim3((unsigned)st.count), dim3(256), 0, F->stream,
-                               P + st.first, F->Dinv.p, X, d, nr);
+            hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
+                               0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -578,12 +610,13 @@ static int solve_host(mi355_factor *F, bool lower, int64_t nrhs, double *X, int6
     if (n == 0 || nrhs == 0) return MI355_OK;
     if (!X) return fail(MI355_INVALID, "null X");
     DevBuf<double> dX;
-    HIP_TRY(dX.alloc((size_t)n * nrhs));
-    HIP_TRY(hipMemcpy2DAsync(dX.p, n * sizeof(double), X, d * sizeof(double), n * sizeof(double),
+    const size_t es = (size_t)F->E * sizeof(double);        // bytes per entry
+    HIP_TRY(dX.alloc((size_t)n * nrhs * F->E));
+    HIP_TRY(hipMemcpy2DAsync(dX.p, n * es, X, d * es, n * es,
                              (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
     rc = solve_dev(F, lower, nrhs, dX.p, n);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(X, d * sizeof(double), dX.p, n * sizeof(double), n * sizeof(double),
+    HIP_TRY(hipMemcpy2DAsync(X, d * es, dX.p, n * es, n * es,
                              (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
     HIP_TRY(hipStreamSynchronize(F->stream));
     return MI355_OK;

@@ -83,7 +83,7 @@ GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int
 // append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
 // kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
 // tile0 prefix sums
-void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level)
+void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_big)
 {
     if (tasks.empty()) return;
     const Tuning &tu = tuning();
@@ -92,7 +92,7 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level)
         st.kind = STEP_GEMM; st.level = level; st.big = big; st.pad = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
         for (auto &t : tasks) {
-            const int is_big = (t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
+            const int is_big = (!no_big && t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
             if (is_big != big) continue;
             int64_t nt = gemm_tiles(t.M, t.N, t.mode, big ? BTILE : TILE);
             if (nt == 0) continue;
@@ -260,10 +260,10 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.stiles = stiles;
             out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
             if (st.count > 0) out.steps.push_back(st);
-            flush_gemm(out, ls.trsm[it], lev);
-            flush_gemm(out, ls.trail[it], lev);
+            flush_gemm(out, ls.trsm[it], lev, S.no_big);
+            flush_gemm(out, ls.trail[it], lev, S.no_big);
         }
-        flush_gemm(out, ls.updates, lev);
+        flush_gemm(out, ls.updates, lev, S.no_big);
     }
 }
 

@@ -83,6 +83,7 @@ struct Step {
 struct Symbolic {
     int64_t n = 0, nsuper = 0, ssize = 0, xsize = 0;
     const int64_t *Super = nullptr, *Lpi = nullptr, *Lpx = nullptr, *Ls = nullptr;
+    bool no_big = false;        // route every GEMM task to the 64x64-tile kernel (complex factors)
 };
 
 struct Schedule {

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
-    "mi355_debug_gemm_rate", "mi355_set_tuning",
+    "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
 ]
 
 _LIB = None
@@ -60,6 +60,7 @@ def lib():
                                           C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
         L.mi355_factor_free.argtypes = [C.c_void_p]
         L.mi355_factor_set_matrix.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p]
+        L.mi355_factor_set_matrix_zomplex.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, _f64p]
         L.mi355_factor_numeric.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int)]
         L.mi355_factor_get_Lx.argtypes = [C.c_void_p, _f64p]
@@ -125,6 +126,8 @@ class SupernodalFactor:
     """Device-resident supernodal factor (cholmod_factor with is_super, CHOLMOD/Include/cholmod.h:1584-1651)."""
 
     def __init__(self, sym, device=0, xtype=1):
+        """xtype: 1 = real L, 2 = complex L (cholmod.h:134-137)"""
+        self.E = 2 if xtype == 2 else 1
         self.n = int(sym["n"])
         self.nsuper = int(sym["nsuper"])
         self.xsize = int(sym["xsize"])
@@ -157,18 +160,29 @@ class SupernodalFactor:
             pass
 
     # ---- numeric ----
-    def set_matrix(self, Sp, Si, Sx, Snz=None):
+    def set_matrix(self, Sp, Si, Sx, Snz=None, Sz=None):
+        """Sx: real array, or complex array (interleaved on the way in) for a complex L;
+        Sz: imaginary parts of a zomplex matrix (then Sx holds the real parts)."""
         Sp = np.ascontiguousarray(Sp, dtype=np.int64)
         Si = np.ascontiguousarray(Si, dtype=np.int64)
-        Sx = np.ascontiguousarray(Sx, dtype=np.float64)
+        if self.E == 2 and Sz is None:
+            Sx = np.ascontiguousarray(Sx, dtype=np.complex128).view(np.float64)
+        else:
+            if np.iscomplexobj(Sx):
+                raise Mi355Error(CHOLMOD_INVALID, "complex type mismatch: complex A with a real L")
+            Sx = np.ascontiguousarray(Sx, dtype=np.float64)
         if Si.size == 0:
             Si = np.zeros(1, dtype=np.int64)
-            Sx = np.zeros(1)
+            Sx = np.zeros(2)
         nz = None
         if Snz is not None:
             self._nz = np.ascontiguousarray(Snz, dtype=np.int64)
             nz = self._nz.ctypes.data_as(C.c_void_p)
-        _check(lib().mi355_factor_set_matrix(self._h, Sp, Si, nz, Sx))
+        if Sz is not None:
+            Sz = np.ascontiguousarray(Sz, dtype=np.float64)
+            _check(lib().mi355_factor_set_matrix_zomplex(self._h, Sp, Si, nz, Sx, Sz))
+        else:
+            _check(lib().mi355_factor_set_matrix(self._h, Sp, Si, nz, Sx))
 
     def numeric(self, beta=0.0, quick_return_if_not_posdef=False):
         """Factorize the staged matrix; everything stays in HBM.  Returns CHOLMOD status."""
@@ -179,30 +193,34 @@ class SupernodalFactor:
         self.minor, self.status = int(minor.value), int(status.value)
         return self.status
 
-    def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None):
+    def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None, Sz=None):
         """cholmod_super_numeric(S, NULL, beta, L): S = tril(P A P'), only beta[0] is used
         (t_cholmod_super_numeric_worker.c:510-520).  Returns Common->status; sets self.minor."""
         b = beta[0] if isinstance(beta, (tuple, list, np.ndarray)) else beta
-        self.set_matrix(Sp, Si, Sx, Snz)
+        self.set_matrix(Sp, Si, Sx, Snz, Sz)
         return self.numeric(b, quick_return_if_not_posdef)
 
     def Lx(self):
-        out = np.zeros(max(self.xsize, 1))
+        out = np.zeros(max(self.xsize, 1) * self.E)
         _check(lib().mi355_factor_get_Lx(self._h, out))
-        return out[:self.xsize]
+        out = out[:self.xsize * self.E]
+        return out.view(np.complex128) if self.E == 2 else out
 
     # ---- solves ----
     def _solve(self, fn, X):
-        X = np.asarray(X, dtype=np.float64)
+        dt = np.complex128 if self.E == 2 else np.float64
+        if self.E == 1 and np.iscomplexobj(X):
+            raise Mi355Error(CHOLMOD_INVALID, "L and X must have the same xtype")
+        X = np.asarray(X, dtype=dt)
         one_d = X.ndim == 1
         if one_d:
             X = X[:, None]
         n, nrhs = X.shape
-        flat = np.ascontiguousarray(X.T).reshape(-1).copy()     # column-major n x nrhs, ld n
-        if flat.size == 0:
+        buf = np.array(X.T, dtype=dt, order="C", copy=True)     # column-major n x nrhs, ld n
+        if buf.size == 0:
             return X.copy()
-        _check(fn(self._h, nrhs, flat, n))
-        out = flat.reshape(nrhs, n).T.copy()
+        _check(fn(self._h, nrhs, buf.view(np.float64).reshape(-1), n))
+        out = buf.T.copy()
         return out[:, 0] if one_d else out
 
     def super_lsolve(self, X):
@@ -238,7 +256,7 @@ class SupernodalFactor:
             class _View:
                 pass
             v = _View()
-            v.__cuda_array_interface__ = {"shape": (int(hi - lo),), "typestr": "<f8", "data": (base + 8 * int(lo), False),
+            v.__cuda_array_interface__ = {"shape": (int(hi - lo) * self.E,), "typestr": "<f8", "data": (base + 8 * self.E * int(lo), False),
                                           "version": 2}
             out.append(torch.as_tensor(v, device="cuda"))
         return out

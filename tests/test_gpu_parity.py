@@ -25,13 +25,11 @@ def engine():
     return e
 
 
-REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
-
-
-@pytest.mark.parametrize("name", REAL)
+@pytest.mark.parametrize("name", golden_names())
 def test_golden_factor_and_solve(engine, name):
+    """every committed fixture, real and complex (the cd_/zd_ worker instantiations)"""
     g = load_golden(name)
-    L = engine.SupernodalFactor(sym_of(g))
+    L = engine.SupernodalFactor(sym_of(g), xtype=g["xtype"])
     st = L.super_numeric(g["Sp"], g["Si"], g["Sx"], beta=(g["beta"], 0.0))
     Lx = L.Lx()
     assert st == g["status"]
@@ -177,9 +175,11 @@ def test_error_paths(engine):
     with pytest.raises(engine.Mi355Error):
         engine.SupernodalFactor(bad)
     with pytest.raises(engine.Mi355Error) as ei:
-        engine.SupernodalFactor(sym, xtype=2)                        # complex: CPU worker's job for now
-    assert ei.value.code == engine.CHOLMOD_NOT_INSTALLED
+        engine.SupernodalFactor(sym, xtype=3)                        # L is never zomplex
+    assert ei.value.code == engine.CHOLMOD_INVALID
     L = engine.SupernodalFactor(sym)
+    with pytest.raises(engine.Mi355Error):
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"] + 0j)                 # complex A, real L: type mismatch
     with pytest.raises(engine.Mi355Error):
         L.numeric()                                                  # no matrix staged
     with pytest.raises(engine.Mi355Error):
@@ -234,3 +234,40 @@ def test_multigpu_phases_simulated_on_one_gpu(engine, world):
             if owner[s] in (r, -1):
                 a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
                 assert relerr(Lx[a:b], Lo[a:b]) < TOL_L
+
+
+def test_zomplex_input_gives_complex_factor(engine):
+    """A zomplex (split re/im), L complex: the zd_ instantiation (worker :69-83)"""
+    g = load_golden("tcov_z30lo")
+    L = engine.SupernodalFactor(sym_of(g), xtype=2)
+    Sx = np.asarray(g["Sx"])
+    st = L.super_numeric(g["Sp"], g["Si"], np.ascontiguousarray(Sx.real), Sz=np.ascontiguousarray(Sx.imag))
+    assert st == 0 and relerr(L.Lx(), g["Lx"]) < TOL_L
+
+
+@pytest.mark.parametrize("size,nrhs", [(12, 1), (16, 5)])
+def test_complex_hermitian_vs_live_reference(engine, size, nrhs, have_ref):
+    """config-5 shaped problem (complex Hermitian shifted Laplacian) incl. multi-RHS solve"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = problems.helmholtz_3d(size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    L = engine.SupernodalFactor(sym, xtype=2)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    Lx = L.Lx()
+    assert relerr(Lx, r.Lx()) < TOL_L
+    B = problems.demo_rhs(p["n"], nrhs, True)
+    Bp = B[sym["Perm"]]
+    Xg = L.super_ltsolve(L.super_lsolve(Bp))
+    Xr = r.super_solve(r.super_solve(Bp, True), False)
+    assert relerr(Xg, Xr) < 1e-9
+    X = np.empty_like(Xg)
+    X[sym["Perm"]] = Xg
+    assert problems.backward_error(p, X, B) <= 10 * problems.backward_error(p, r.solve(B), B) + 1e-18
