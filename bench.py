@@ -40,6 +40,8 @@ def make_problem(kind, grid):
         return problems.laplacian_2d(grid), f"2D 5-point Laplacian {grid}^2"
     if kind == "elast":
         return problems.elasticity27(grid), f"3D 27-point 3-dof elasticity-like {grid}^3"
+    if kind == "helm":
+        return problems.helmholtz_3d(grid), f"complex Hermitian 3D Helmholtz-shifted Laplacian {grid}^3"
     raise ValueError(kind)
 
 
@@ -87,7 +89,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="grid size (default: the largest named config that fits)")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--solve", action="store_true", help="also time the supernodal solve (nrhs 1)")
+    ap.add_argument("--solve", action="store_true", help="also time the supernodal solve")
+    ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--tune", default="", help="experiments: key=value,... (0 big_min_m, 1 big_min_n, 2 outer block)")
     args = ap.parse_args()
 
@@ -106,13 +109,14 @@ def main():
         k, v = kv.split("=")
         engine.set_tuning(int(k), int(v))
 
-    default_grid = {"lap3d": 150, "lap2d": 2000, "elast": 80}[args.problem]
+    default_grid = {"lap3d": 150, "lap2d": 2000, "elast": 80, "helm": 100}[args.problem]
     grid = args.grid or default_grid
     p, name = make_problem(args.problem, grid)
     sym, (Sp, Si, Sx), t_analyze = analyze(p)
 
     t0 = time.time()
-    L = engine.SupernodalFactor(sym, device=local_rank)
+    cplx = np.iscomplexobj(p["Ax"])
+    L = engine.SupernodalFactor(sym, device=local_rank, xtype=2 if cplx else 1)
     L.set_matrix(Sp, Si, Sx)
     t_setup = time.time() - t0
     if world > 1:
@@ -182,13 +186,15 @@ def main():
         "roofline": roof,
     }
     if args.solve and world == 1:
-        X = torch.ones(p["n"], dtype=torch.float64, device="cuda")
-        L.solve_dev(X.data_ptr(), 1, p["n"], lower=True)
+        E = 2 if cplx else 1
+        nrhs = args.nrhs
+        X = torch.ones(p["n"] * nrhs * E, dtype=torch.float64, device="cuda")
+        L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=True)
         t_f = L.stats()["solve_ms"]
-        L.solve_dev(X.data_ptr(), 1, p["n"], lower=False)
+        L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=False)
         t_b = L.stats()["solve_ms"]
-        bytes_alg = 2 * sym["xsize"] * 8 + 4 * p["n"] * 8
-        out["config"]["solve"] = {"nrhs": 1, "forward_ms": round(t_f, 3), "backward_ms": round(t_b, 3),
+        bytes_alg = (2 * sym["xsize"] * 8 + 4 * p["n"] * nrhs * 8) * E
+        out["config"]["solve"] = {"nrhs": nrhs, "forward_ms": round(t_f, 3), "backward_ms": round(t_b, 3),
                                   "algorithmic_GBs": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9, 1),
                                   "frac_hbm_peak": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)}
     if rank == 0:
@@ -197,7 +203,7 @@ def main():
                 out["config"]["mfma_f64_measured_tflops"] = round(engine.mfma_f64_rate(local_rank), 2)
             except Exception:   # noqa: BLE001
                 pass
-            cg = args.cpu_grid or {"lap3d": 72, "lap2d": 1200, "elast": 30}[args.problem]
+            cg = args.cpu_grid or {"lap3d": 72, "lap2d": 1200, "elast": 30, "helm": 48}[args.problem]
             out["cpu_baseline"] = cpu_baseline(args.problem, min(cg, grid))
         else:
             out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference",

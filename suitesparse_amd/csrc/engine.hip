@@ -70,7 +70,7 @@ struct DeviceSchedule {
     Schedule sched;
     DevBuf<GemmTask> gemm;
     DevBuf<PotrfTask> potrf;
-    DevBuf<int32_t> relmap;
+    DevBuf<int32_t> relmap, gemm_tmap, solve_tmap;
 };
 
 }  // namespace
@@ -119,6 +119,8 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
     Schedule &S = D.sched;
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
+    HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_task.data(), S.gemm_tile_task.size(), F->stream));
+    HIP_TRY(D.solve_tmap.upload(S.solve_tile_task.data(), S.solve_tile_task.size(), F->stream));
     HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
     if (S.relmap_size > 0) {
         std::vector<RelmapPair> rp(S.pairs.size());
@@ -220,13 +222,14 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             tm.begin(0);
             if (cplx)
                 hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
-                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             else if (st.big)
-                hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
-                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+                hipLaunchKernelGGL(tuning().mfma444 ? k_gemm128<true> : k_gemm128<false>, dim3((unsigned)st.ntiles),
+                                   dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             else
                 hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
-                                   D.gemm.p + st.first, (int)st.count, F->Lx.p, F->Dinv.p, D.relmap.p);
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             tm.end(0);
             F->st_ngemm += 1;
             F->st_tiles += (double)st.ntiles;
@@ -574,8 +577,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             if (st.stiles > 0)
                 hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
-                                   dim3(SOLVE_ROWS), 0, F->stream,
-                                   P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
+                                   dim3(cplx ? SOLVE_ROWS : 256), 0, F->stream,
+                                   P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
             HIP_TRY(hipGetLastError());
         }
     } else {
@@ -584,8 +587,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
             if (st.stiles > 0)
                 hipLaunchKernelGGL(cplx ? k_solve_bwd_update_c : k_solve_bwd_update, dim3((unsigned)st.stiles),
-                                   dim3(SOLVE_ROWS), 0, F->stream,
-                                   P + st.first, (int)st.count, F->Lx.p, F->dLs.p, X, d, nr);
+                                   dim3(256), 0, F->stream,
+                                   P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
             hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
                                0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             HIP_TRY(hipGetLastError());
@@ -677,6 +680,7 @@ int mi355_set_tuning(int key, int value)
     if (key == 0) tuning().big_min_m = value;
     else if (key == 1) tuning().big_min_n = value;
     else if (key == 2) tuning().ob = value;
+    else if (key == 3) tuning().mfma444 = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -703,15 +707,20 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     DevBuf<GemmTask> dt;
     HIP_TRY(dt.upload(&t, 1, 0));
     const int64_t ntiles = gemm_tiles(M, N, t.mode, kernel ? BTILE : TILE);
+    DevBuf<int32_t> dmap;
+    HIP_TRY(dmap.alloc((size_t)ntiles));
+    HIP_TRY(hipMemset(dmap.p, 0, (size_t)ntiles * sizeof(int32_t)));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int it = -2; it < iters; it++) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
-        if (kernel)
-            hipLaunchKernelGGL(k_gemm128, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, 1, buf.p, buf.p, (const int32_t *)nullptr);
+        if (kernel == 1)
+            hipLaunchKernelGGL(k_gemm128<true>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
+        else if (kernel == 2)
+            hipLaunchKernelGGL(k_gemm128<false>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
         else
-            hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, 1, buf.p, buf.p, (const int32_t *)nullptr);
+            hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
     }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));

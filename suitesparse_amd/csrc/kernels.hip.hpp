@@ -122,7 +122,7 @@ constexpr int G64_KS = 16;          // K per LDS stage
 constexpr int G64_LD = 80;          // padded row stride (doubles): 640 B, lanes 16..31 land on banks 32..63
 
 __global__ __launch_bounds__(256) void k_gemm64(
-    const GemmTask *__restrict__ tasks, int ntasks, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double As[G64_KS][G64_LD];
@@ -131,12 +131,7 @@ __global__ __launch_bounds__(256) void k_gemm64(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
-    }
-    const GemmTask t = tasks[lo];
+    const GemmTask t = tasks[tile_task[bid]];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
     const int MT = (M + TILE - 1) / TILE, NT = (N + TILE - 1) / TILE;
     int tm, tn;
@@ -195,6 +190,24 @@ __global__ __launch_bounds__(256) void k_gemm64(
     // epilogue.  D row = (lane>>4) + 4*r  <-> n ; D col = lane & 15 <-> m
     const int64_t ldc = t.ldc;
     double *__restrict__ C = Lx + t.c_off;
+    if (mode == GEMM_DIRECT_SUB) {
+        // batched read-modify-write: 16 loads in flight before the first use
+        double cv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int m = m0 + wm * 32 + ((q >> 2) & 1) * 16 + l15;
+            const int n = n0 + wn * 32 + (q >> 3) * 16 + l4 + 4 * (q & 3);
+            const bool ok = (m < M) && (n < N) && (m >= n);
+            cv[q] = C[ok ? (m + (int64_t)n * ldc) : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int m = m0 + wm * 32 + ((q >> 2) & 1) * 16 + l15;
+            const int n = n0 + wn * 32 + (q >> 3) * 16 + l4 + 4 * (q & 3);
+            if ((m < M) && (n < N) && (m >= n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 3][(q >> 2) & 1][q & 3];
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) {
 #pragma unroll
@@ -230,8 +243,18 @@ __global__ __launch_bounds__(256) void k_gemm64(
 constexpr int G128_KS = 16;
 constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row => conflict-free ds_read_b64
 
+// MFMA444 = true: the inner product runs on v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64.
+// Measured on MI355X (profiles/r01_mfma_f64_probe.txt): one wave issues a 16x16x4 f64 MFMA only every
+// ~140 cycles (47 TFLOP/s chip-wide at best, 4 waves/SIMD) while the 4-block 4x4x4 form issues every
+// 17.5 cycles (64 TFLOP/s with ONE wave per SIMD) -- the vendor FP64-matrix peak is a 4x4x4 number.
+// Lane layout of the 4x4x4 form (probed, tools/probes/mfma444_layout.hip): lane l = 16k + 4b + x feeds
+// A_b[x][k] and B_b[k][x]; D_b[i][j] lands in lane 16i + 4b + j.  Feeding the B-matrix rows
+// (n = 4rn + x, the same for all four blocks) as the first operand and the A-matrix rows
+// (m = 16rm + 4b + x = 16rm + lane%16) as the second makes one instruction a (16 m) x (4 n) x (4 k)
+// product whose result has m along lane%16 and n along lane/16 -- the same store pattern as before.
+template <bool MFMA444>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
-    const GemmTask *__restrict__ tasks, int ntasks, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double As[2][G128_KS][G128_LD];
@@ -240,12 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
-    }
-    const GemmTask t = tasks[lo];
+    const GemmTask t = tasks[tile_task[bid]];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
     const int MT = (M + BTILE - 1) / BTILE, NT = (N + BTILE - 1) / BTILE;
     int tm, tn;
@@ -268,7 +286,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     // a diagonal tile of a lower-trapezoid task needs nothing from its strictly upper 64x64 quadrant
     const bool skip_mma = (mode != GEMM_OVERWRITE) && (m0 == n0) && (wm < wn);
 
-    v4d acc[4][4];                               // [ni][mi]
+    // 64 accumulator doubles per lane either way: 16x16x4: acc[ni][mi][r] ; 4x4x4: c[rn = 4*ni + r][rm = mi]
+    // -- in both cases element (ni, mi, r) is C[m = 16*mi + lane%16][n = 16*ni + 4*r + lane/16] of the wave tile
+    v4d acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -308,17 +328,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const int kk = ks * 4 + l4;
-                double a[4], b[4];
+                if constexpr (MFMA444) {
+                    double a[4], b[16];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
-                    b[i] = Bs[buf][kk][wn * 64 + i * 16 + l15];
+                    for (int i = 0; i < 4; i++) a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) b[j] = Bs[buf][kk][wn * 64 + j * 4 + (lane & 3)];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int mi = 0; mi < 4; mi++)
+                                acc[ni][mi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(b[4 * ni + r], a[mi], acc[ni][mi][r], 0, 0, 0);
+                } else {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
+                        b[i] = Bs[buf][kk][wn * 64 + i * 16 + l15];
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                        for (int mi = 0; mi < 4; mi++)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
                 }
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                    for (int mi = 0; mi < 4; mi++)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
             }
         }
         if (more) lstore(buf ^ 1);
@@ -329,6 +364,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 
     const int64_t ldc = t.ldc;
     double *__restrict__ C = Lx + t.c_off;
+    if (mode == GEMM_DIRECT_SUB) {
+        // read-modify-write in batches of 16: all loads of a batch are issued before the first use, so
+        // the wave waits for memory once per batch instead of once per element
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const int m = m0 + wm * 64 + mi * 16 + l15;
+            double cv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int n = n0 + wn * 64 + (q >> 2) * 16 + (MFMA444 ? (4 * (q & 3) + l4) : (l4 + 4 * (q & 3)));
+                const bool ok = (m < M) && (n < N) && (m >= n);
+                cv[q] = C[ok ? (m + (int64_t)n * ldc) : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int n = n0 + wn * 64 + (q >> 2) * 16 + (MFMA444 ? (4 * (q & 3) + l4) : (l4 + 4 * (q & 3)));
+                if ((m < M) && (n < N) && (m >= n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 2][mi][q & 3];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ni++) {
 #pragma unroll
@@ -337,14 +393,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
             const int m = m0 + ml;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int nl = wn * 64 + ni * 16 + l4 + 4 * r;
+                // 16x16x4: D row (n) = lane/16 + 4r ; 4x4x4: n = 4*(4ni + r) + lane/16
+                const int nl = wn * 64 + ni * 16 + (MFMA444 ? (4 * r + l4) : (l4 + 4 * r));
                 const int n = n0 + nl;
                 if (m < M && n < N) {
                     const double v = acc[ni][mi][r];
                     if (mode == GEMM_SCATTER_SUB) {
                         if (m >= n) atomic_add_f64(C + rmM[ml] + (int64_t)rmN[nl] * ldc, -v);
-                    } else if (mode == GEMM_DIRECT_SUB) {
-                        if (m >= n) C[m + (int64_t)n * ldc] -= v;
                     } else {
                         C[m + (int64_t)n * ldc] = v;
                     }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_assemble_c(
 // k_gemm64c: complex C = A * B^H, 64x64 tile, 4 waves (2x2), 2x2 MFMA blocks x {re,im}
 //------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gemm64c(
-    const GemmTask *__restrict__ tasks, int ntasks, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double Ar[G64_KS][G64_LD], Ai_[G64_KS][G64_LD];
@@ -59,12 +59,7 @@ __global__ __launch_bounds__(256) void k_gemm64c(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
-    }
-    const GemmTask t = tasks[lo];
+    const GemmTask t = tasks[tile_task[bid]];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
     const int MT = (M + TILE - 1) / TILE, NT = (N + TILE - 1) / TILE;
     int tm, tn;
@@ -303,17 +298,12 @@ __global__ __launch_bounds__(256) void k_solve_diag_c(
 }
 
 __global__ __launch_bounds__(SOLVE_ROWS) void k_solve_fwd_update_c(
-    const PotrfTask *__restrict__ tasks, int ntasks, const double *__restrict__ Lx,
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, const double *__restrict__ Lx,
     const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
 {
     constexpr int NR = 2;
     __shared__ double yr[NB][NR], yi[NB][NR];
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].stile0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const PotrfTask t = tasks[lo];
+    const PotrfTask t = tasks[tile_task[blockIdx.x]];
     const int tid = threadIdx.x, nb = t.nb;
     const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + tid;
     const bool ok = r < t.lda;
@@ -355,20 +345,15 @@ __global__ __launch_bounds__(SOLVE_ROWS) void k_solve_fwd_update_c(
 }
 
 // backward: x1[c] -= sum_r conj(L[r][col0+c]) * X[row(r)]
-__global__ __launch_bounds__(SOLVE_ROWS) void k_solve_bwd_update_c(
-    const PotrfTask *__restrict__ tasks, int ntasks, const double *__restrict__ Lx,
+__global__ __launch_bounds__(256) void k_solve_bwd_update_c(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, const double *__restrict__ Lx,
     const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
 {
     constexpr int NR = 2;
     __shared__ double Tr[64][NB + 1], Ti[64][NB + 1];
     __shared__ double xr[64][NR], xi[64][NR];
     __shared__ double redr[4][NB][NR], redi[4][NB][NR];
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].stile0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const PotrfTask t = tasks[lo];
+    const PotrfTask t = tasks[tile_task[blockIdx.x]];
     const int tid = threadIdx.x, nb = t.nb;
     const int rbase = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS;
     const int c = tid & 63, part = tid >> 6;

@@ -91,6 +91,7 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_
         Step st;
         st.kind = STEP_GEMM; st.level = level; st.big = big; st.pad = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
+        st.tmap_off = (int64_t)out.gemm_tile_task.size();
         for (auto &t : tasks) {
             const int is_big = (!no_big && t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
             if (is_big != big) continue;
@@ -100,6 +101,7 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_
             t.tile0 = st.ntiles;
             st.ntiles += nt;
             out.gemm.push_back(t);
+            out.gemm_tile_task.insert(out.gemm_tile_task.end(), (size_t)nt, (int32_t)st.count);
             st.count++;
         }
         if (st.count > 0) out.steps.push_back(st);
@@ -247,10 +249,15 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 out.dinv_size += (int64_t)pt.nb * pt.nb;
             }
             int64_t stiles = 0;
+            const int64_t tmap_off = (int64_t)out.solve_tile_task.size();
+            int32_t ti32 = 0;
             for (auto &pt : ls.potrf[it]) {
                 const int64_t below = (int64_t)pt.lda - (pt.col0 + pt.nb);
+                const int64_t nt = (below + SOLVE_ROWS - 1) / SOLVE_ROWS;
                 pt.stile0 = stiles;
-                stiles += (below + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                stiles += nt;
+                out.solve_tile_task.insert(out.solve_tile_task.end(), (size_t)nt, ti32);
+                ti32++;
             }
             Step st;
             st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.pad = 0;
@@ -258,6 +265,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.count = (int64_t)ls.potrf[it].size();
             st.ntiles = st.count;
             st.stiles = stiles;
+            st.tmap_off = tmap_off;
             out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
             if (st.count > 0) out.steps.push_back(st);
             flush_gemm(out, ls.trsm[it], lev, S.no_big);

@@ -25,7 +25,7 @@ constexpr int NB = 64;        // diagonal-block / panel width of the device POTR
 constexpr int OB = 512;       // outer block (trailing updates with K = OB); 512 measured best at 150^3
 constexpr int TILE = 64;      // GEMM output tile (TILE x TILE per workgroup), small-tile kernel
 constexpr int BTILE = 128;    // big-tile kernel
-constexpr int SOLVE_ROWS = 256;  // rows of L per workgroup in the solve update kernels
+constexpr int SOLVE_ROWS = 64;   // rows of L per workgroup (tile) in the solve update kernels
 
 enum GemmMode : int32_t {
     GEMM_SCATTER_SUB = 0,     // Lx[c_off + rm[i] + rm[j]*ldc] -= C(i,j), i>=j, atomic   (a3.5-a3.8)
@@ -78,6 +78,7 @@ struct Step {
     int64_t count;      // number of tasks
     int64_t ntiles;     // STEP_GEMM: total tiles (= grid size); STEP_POTRF: = count
     int64_t stiles;     // STEP_POTRF: row tiles (SOLVE_ROWS rows each) below the blocks, for the solves
+    int64_t tmap_off;   // offset of this step's tile -> task table (gemm_tile_task / solve_tile_task)
 };
 
 struct Symbolic {
@@ -95,6 +96,9 @@ struct Schedule {
     std::vector<GemmTask> gemm;
     std::vector<UpdatePair> pairs;
     std::vector<Step> steps;
+    // tile -> task (index relative to the step's first task), one int32 per workgroup: a workgroup
+    // finds its task with ONE load instead of a binary search of dependent loads
+    std::vector<int32_t> gemm_tile_task, solve_tile_task;
     int64_t relmap_size = 0;            // total relative-map entries (sum of ndrow2 over pairs)
     int64_t dinv_size = 0;              // total entries of the block inverses (sum nb^2)
     // truncation (not-positive-definite repeat, worker :1084-1146); s_limit == nsuper: none
@@ -120,7 +124,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     const int8_t *mask = nullptr);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; int mfma444 = 0; };
 Tuning &tuning();
 
 // number of TILE-tiles of one task

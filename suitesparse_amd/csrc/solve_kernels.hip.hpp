@@ -20,149 +20,167 @@ namespace mi355 {
 constexpr int SOLVE_NR = 4;      // right-hand sides per register pass
 
 // x1 <- inv(L11) x1  (TRANS = false)   or   x1 <- inv(L11)^T x1  (TRANS = true)
+// One workgroup per block.  Dinv is read straight from global memory (column-major, ld nb): for a
+// fixed k the 64 lanes of a wave read 64 consecutive doubles; the k range is split over the 4 waves
+// and reduced through LDS, so no lane runs a 64-long dependent chain.
 template <bool TRANS>
 __global__ __launch_bounds__(256) void k_solve_diag(
     const PotrfTask *__restrict__ tasks, const double *__restrict__ Dinv,
     double *__restrict__ X, int64_t ldx, int nrhs)
 {
-    __shared__ double Ds[NB][NB + 1];
-    __shared__ double xs[NB][16 + 1];
+    __shared__ double xs[NB][SOLVE_NR];
+    __shared__ double red[4][NB][SOLVE_NR];
     const PotrfTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, nb = t.nb;
+    const int i = tid & 63, part = tid >> 6;
     const double *__restrict__ D = Dinv + t.dinv_off;
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int i = idx % nb, j = idx / nb;
-        Ds[i][j] = D[idx];
-    }
     double *__restrict__ x1 = X + t.k1 + t.col0;
-    for (int j0 = 0; j0 < nrhs; j0 += 16) {
-        const int nj = min(16, nrhs - j0);
-        __syncthreads();
-        for (int idx = tid; idx < nb * nj; idx += 256) {
-            const int i = idx % nb, j = idx / nb;
-            xs[i][j] = x1[i + (int64_t)(j0 + j) * ldx];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < nb * nj; idx += 256) {
-            const int i = idx % nb, j = idx / nb;
-            double acc = 0.0;
-            if (!TRANS) { for (int k = 0; k <= i; k++) acc += Ds[i][k] * xs[k][j]; }
-            else        { for (int k = i; k < nb; k++) acc += Ds[k][i] * xs[k][j]; }
-            x1[i + (int64_t)(j0 + j) * ldx] = acc;
-        }
-    }
-}
-
-// locate the block (task) of a row tile
-__device__ __forceinline__ int find_solve_task(const PotrfTask *__restrict__ tasks, int ntasks, int64_t tile)
-{
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].stile0 <= tile) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-// forward: X[row(r)] -= sum_c L[r][col0+c] * x1[c]   for SOLVE_ROWS rows r below the block
-__global__ __launch_bounds__(SOLVE_ROWS) void k_solve_fwd_update(
-    const PotrfTask *__restrict__ tasks, int ntasks, const double *__restrict__ Lx,
-    const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
-{
-    __shared__ double ys[NB][SOLVE_NR];
-    const int ti = find_solve_task(tasks, ntasks, blockIdx.x);
-    const PotrfTask t = tasks[ti];
-    const int tid = threadIdx.x, nb = t.nb;
-    const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + tid;   // row inside s
-    const bool ok = r < t.lda;
-    const double *__restrict__ Lr = Lx + t.a_off + (r - t.col0);                   // L[r][col0]
-    int64_t row = 0;
-    if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
-    const double *__restrict__ x1 = X + t.k1 + t.col0;
     for (int j0 = 0; j0 < nrhs; j0 += SOLVE_NR) {
         const int nj = min(SOLVE_NR, nrhs - j0);
         __syncthreads();
-        for (int idx = tid; idx < nb * SOLVE_NR; idx += SOLVE_ROWS) {
+        for (int idx = tid; idx < nb * SOLVE_NR; idx += 256) {
+            const int r = idx % nb, j = idx / nb;
+            xs[r][j] = (j < nj) ? x1[r + (int64_t)(j0 + j) * ldx] : 0.0;
+        }
+        __syncthreads();
+        double acc[SOLVE_NR];
+#pragma unroll
+        for (int j = 0; j < SOLVE_NR; j++) acc[j] = 0.0;
+        if (i < nb) {
+            // y_i = sum_k D(i,k) x_k (k <= i)   or   sum_k D(k,i) x_k (k >= i)
+            const int klo = TRANS ? i : 0, khi = TRANS ? nb : i + 1;
+            for (int k = klo + part; k < khi; k += 4) {
+                const double d = TRANS ? D[k + i * nb] : D[i + k * nb];
+#pragma unroll
+                for (int j = 0; j < SOLVE_NR; j++) acc[j] += d * xs[k][j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SOLVE_NR; j++) red[part][i][j] = acc[j];
+        __syncthreads();
+        if (part == 0 && i < nb) {
+#pragma unroll
+            for (int j = 0; j < SOLVE_NR; j++)
+                if (j < nj) x1[i + (int64_t)(j0 + j) * ldx] = red[0][i][j] + red[1][i][j] + red[2][i][j] + red[3][i][j];
+        }
+    }
+}
+
+// forward: X[row(r)] -= sum_c L[r][col0+c] * x1[c]  for the SOLVE_ROWS (64) rows r of one tile.
+// 256 threads: lane = row, wave w owns columns [16w, 16w+16): 16 independent coalesced loads per
+// lane in flight, partial sums reduced over the 4 waves through LDS, one atomic per row and rhs.
+__global__ __launch_bounds__(256) void k_solve_fwd_update(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, const double *__restrict__ Lx,
+    const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
+{
+    __shared__ double ys[NB][SOLVE_NR];
+    __shared__ double red[4][SOLVE_ROWS][SOLVE_NR];
+    const PotrfTask t = tasks[tile_task[blockIdx.x]];
+    const int tid = threadIdx.x, nb = t.nb;
+    const int rl = tid & 63, w = tid >> 6;
+    const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + rl;     // row inside s
+    const bool ok = r < t.lda;
+    const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);     // L[r][col0]
+    const double *__restrict__ x1 = X + t.k1 + t.col0;
+    double l[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = w * 16 + q;
+        l[q] = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
+    }
+    for (int j0 = 0; j0 < nrhs; j0 += SOLVE_NR) {
+        const int nj = min(SOLVE_NR, nrhs - j0);
+        __syncthreads();
+        for (int idx = tid; idx < nb * SOLVE_NR; idx += 256) {
             const int c = idx % nb, j = idx / nb;
             ys[c][j] = (j < nj) ? x1[c + (int64_t)(j0 + j) * ldx] : 0.0;
         }
         __syncthreads();
-        if (ok) {
-            double acc[SOLVE_NR];
+        double acc[SOLVE_NR];
 #pragma unroll
-            for (int j = 0; j < SOLVE_NR; j++) acc[j] = 0.0;
-            for (int c = 0; c < nb; c++) {
-                const double l = Lr[(int64_t)c * t.lda];
+        for (int j = 0; j < SOLVE_NR; j++) acc[j] = 0.0;
 #pragma unroll
-                for (int j = 0; j < SOLVE_NR; j++) acc[j] += l * ys[c][j];
+        for (int q = 0; q < 16; q++) {
+            const int c = w * 16 + q;
+            if (c < nb) {
+#pragma unroll
+                for (int j = 0; j < SOLVE_NR; j++) acc[j] += l[q] * ys[c][j];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < SOLVE_NR; j++) red[w][rl][j] = acc[j];
+        __syncthreads();
+        if (w == 0 && ok) {
+            const int64_t row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
 #pragma unroll
             for (int j = 0; j < SOLVE_NR; j++)
-                if (j < nj) atomic_add_f64(X + row + (int64_t)(j0 + j) * ldx, -acc[j]);
+                if (j < nj)
+                    atomic_add_f64(X + row + (int64_t)(j0 + j) * ldx,
+                                   -(red[0][rl][j] + red[1][rl][j] + red[2][rl][j] + red[3][rl][j]));
         }
     }
 }
 
-// backward: x1[c] -= sum_r L[r][col0+c] * X[row(r)]   over SOLVE_ROWS rows r below the block
-__global__ __launch_bounds__(SOLVE_ROWS) void k_solve_bwd_update(
-    const PotrfTask *__restrict__ tasks, int ntasks, const double *__restrict__ Lx,
+// Sums, over the 64 lanes of the wave, 8 values per lane at once ("transpose-reduce"): three
+// halving exchanges (lane bits 5,4,3) leave one value per lane -- the partial sum of column
+// b5*4 + b4*2 + b3 over 8 lanes -- and three plain exchanges (bits 2,1,0) finish it: 10 shuffles
+// instead of 8 x 6.  On return lane q (q < 8) holds the complete sum of column q.
+__device__ __forceinline__ double wave_colsum8(double (&v)[8], int lane)
+{
+#pragma unroll
+    for (int h = 4, bit = 32; h >= 1; h >>= 1, bit >>= 1) {
+        const bool upper = (lane & bit) != 0;
+#pragma unroll
+        for (int q = 0; q < h; q++) {
+            const double keep = upper ? v[q + h] : v[q];
+            const double send = upper ? v[q] : v[q + h];
+            v[q] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    double x = v[0];
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 1, 64);
+    // lane q (< 8) fetches column q from the lane whose bits 5,4,3 spell q
+    const int src = ((lane >> 2) & 1) * 32 + ((lane >> 1) & 1) * 16 + (lane & 1) * 8;
+    return __shfl(x, src, 64);
+}
+
+// backward: x1[c] -= sum_r L[r][col0+c] * X[row(r)]  over the 64 rows r of one tile.
+// lane = row, wave w owns columns [16w, 16w+16) (a wave without columns leaves at once: most
+// supernodes are narrower than 16); the 64-lane sums are formed with two transpose-reduces per
+// rhs, lanes 0..7 issue the atomics.
+__global__ __launch_bounds__(256) void k_solve_bwd_update(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, const double *__restrict__ Lx,
     const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
 {
-    __shared__ double T[64][NB + 1];            // 64 rows x nb columns of L
-    __shared__ double xs[64][SOLVE_NR];
-    __shared__ double red[4][NB][SOLVE_NR];
-    const int ti = find_solve_task(tasks, ntasks, blockIdx.x);
-    const PotrfTask t = tasks[ti];
+    const PotrfTask t = tasks[tile_task[blockIdx.x]];
     const int tid = threadIdx.x, nb = t.nb;
-    const int rbase = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS;
-    const int c = tid & 63, part = tid >> 6;
+    const int lane = tid & 63, w = tid >> 6;
+    if (w * 16 >= nb) return;                       // no barrier in this kernel
+    const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + lane;
+    const bool ok = r < t.lda;
+    const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
     double *__restrict__ x1 = X + t.k1 + t.col0;
-    for (int j0 = 0; j0 < nrhs; j0 += SOLVE_NR) {
-        const int nj = min(SOLVE_NR, nrhs - j0);
-        double acc[SOLVE_NR];
+    double l[16];
 #pragma unroll
-        for (int j = 0; j < SOLVE_NR; j++) acc[j] = 0.0;
-        for (int sub = 0; sub < SOLVE_ROWS / 64; sub++) {
-            const int r0 = rbase + sub * 64;
-            if (r0 >= t.lda) break;                                 // uniform
-            __syncthreads();
-            {   // stage 64 rows x nb cols of L (lanes along rows: coalesced) and the X rows
-                const int rl = tid & 63, r = r0 + rl;
-                const bool ok = r < t.lda;
-                const double *__restrict__ Lr = Lx + t.a_off + (r - t.col0);
-                for (int cc = (tid >> 6); cc < nb; cc += 4)
-                    T[rl][cc] = ok ? Lr[(int64_t)cc * t.lda] : 0.0;
-                if (tid < 64) {
-                    int64_t row = 0;
-                    if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+    for (int q = 0; q < 16; q++) {
+        const int c = w * 16 + q;
+        l[q] = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
+    }
+    int64_t row = 0;
+    if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+    for (int j = 0; j < nrhs; j++) {
+        const double xr = ok ? X[row + (int64_t)j * ldx] : 0.0;
 #pragma unroll
-                    for (int j = 0; j < SOLVE_NR; j++)
-                        xs[rl][j] = (ok && j < nj) ? X[row + (int64_t)(j0 + j) * ldx] : 0.0;
-                }
-            }
-            __syncthreads();
-            if (c < nb) {
-                for (int rr = part * 16; rr < part * 16 + 16; rr++) {
-                    const double l = T[rr][c];
+        for (int half = 0; half < 2; half++) {
+            if (w * 16 + half * 8 >= nb) break;     // wave-uniform
+            double v[8];
 #pragma unroll
-                    for (int j = 0; j < SOLVE_NR; j++) acc[j] += l * xs[rr][j];
-                }
-            }
-        }
-        __syncthreads();
-        if (c < nb) {
-#pragma unroll
-            for (int j = 0; j < SOLVE_NR; j++) red[part][c][j] = acc[j];
-        }
-        __syncthreads();
-        if (part == 0 && c < nb) {
-#pragma unroll
-            for (int j = 0; j < SOLVE_NR; j++) {
-                if (j < nj) {
-                    const double v = red[0][c][j] + red[1][c][j] + red[2][c][j] + red[3][c][j];
-                    atomic_add_f64(x1 + c + (int64_t)(j0 + j) * ldx, -v);
-                }
-            }
+            for (int q = 0; q < 8; q++) v[q] = l[half * 8 + q] * xr;
+            const double s = wave_colsum8(v, lane);
+            const int c = w * 16 + half * 8 + lane;
+            if (lane < 8 && c < nb) atomic_add_f64(x1 + c + (int64_t)j * ldx, -s);
         }
     }
 }
