@@ -139,7 +139,6 @@ def main():
     L.set_profile(True)
     sync()
     t0 = time.time()
-    gemm_ms = gemm_launches = 0.0
     for _ in range(args.steps):
         step()
         # (per-launch HIP events of this step are read back after the timed region of the LAST step only)
@@ -154,21 +153,33 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     gflops = sym["fl"] / (elapsed / args.steps) * 1e-9
 
-    # roofline of the dominant kernel (k_gemm64): algorithmic flops = Common->fl scaled by the GEMM
-    # share of the executed flops, per launch, over the mean launch duration measured with HIP
-    # events on the engine's stream during the last timed step
-    exec_total = st["flops_update"] + st["flops_panel"]
-    gemm_exec = st["flops_update"] + st["flops_panel"] - sym_potrf_flops(sym)
-    share = gemm_exec / exec_total if exec_total > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": "k_gemm64", "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS,
+    # roofline of the dominant kernel, k_gemm128 (FP64 MFMA): ALGORITHMIC flops per launch = Common->fl
+    # x (share of the executed useful flops that k_gemm128's tasks carry) / launches, over the mean launch
+    # duration measured with HIP events on the engine's stream during the last timed step
+    f128, f64_, fpotrf = st["flops_gemm128"], st["flops_gemm64"], sym_potrf_flops(sym)
+    exec_total = f128 + f64_ + fpotrf
+    share = f128 / exec_total if exec_total > 0 else 0.0
+    big_ms, big_n = st["gemm128_ms"], st["gemm128_launches"]
+    roof = {"bound": "mfma", "kernel": "k_gemm128", "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": None, "traffic": None}
-    if gemm_ms > 0 and gemm_launches > 0:
-        alg_per_launch = sym["fl"] * share / gemm_launches
-        mean_s = gemm_ms * 1e-3 / gemm_launches
+    if big_ms > 0 and big_n > 0:
+        alg_per_launch = sym["fl"] * share / big_n
+        mean_s = big_ms * 1e-3 / big_n
         ach = alg_per_launch / mean_s * 1e-12
         roof.update(achieved=round(ach, 3), frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
-                    launches=int(gemm_launches), mean_launch_ms=round(mean_s * 1e3, 4),
-                    algorithmic_flops_per_launch=alg_per_launch)
+                    launches=int(big_n), mean_launch_ms=round(mean_s * 1e3, 4),
+                    algorithmic_flops_per_launch=alg_per_launch, share_of_fl=round(share, 4))
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
+        # (FETCH_SIZE x2 on gfx950, WRITE_SIZE; tools/pmc_traffic.py), when one exists
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.problem}{grid}.json")
+        if world == 1 and os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc))
+                key = [k for k in t if "k_gemm128" in k][0]
+                roof["traffic"] = t[key]["bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(pmc, ROOT)
+            except Exception:   # noqa: BLE001
+                pass
     out = {
         "metric": "numeric factorization GFLOP/s (CHOLMOD flop count)", "value": round(gflops, 2),
         "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -139,7 +139,7 @@ double *mi355_factor_device_Lx(mi355_factor *handle);
  * engine's stream. */
 int mi355_factor_set_profile(mi355_factor *handle, int profile);
 
-/* out[0..15]: 0 total ms of the last numeric call (events on the engine stream)
+/* out[0..23]: 0 total ms of the last numeric call (events on the engine stream)
  *             1 ms in update/trailing/trsm GEMM launches   2 number of GEMM launches
  *             3 ms in POTRF launches                       4 number of POTRF launches
  *             5 ms in assembly (memset + A scatter)        6 executed GEMM flops
@@ -147,8 +147,11 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *             9 number of (d,s) update pairs              10 number of levels
  *            11 relative-map entries                      12 block-inverse entries
  *            13 ms of the last solve call                 14 GEMM tiles launched
- *            15 reserved */
-int mi355_factor_get_stats(mi355_factor *handle, double *out16);
+ *            15 reserved
+ *            16 ms in k_gemm128 launches (part of 1)      17 number of k_gemm128 launches
+ *            18 useful flops of the tasks in k_gemm128    19 useful flops of the tasks in k_gemm64
+ *            20 k_gemm128 tiles per factorization         21 k_gemm64 tiles        22-23 reserved */
+int mi355_factor_get_stats(mi355_factor *handle, double *out24);
 
 /* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device` (no counterpart in the reference;
  * used by bench.py to state the FP64 matrix peak next to the vendor figure).

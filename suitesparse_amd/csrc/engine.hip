@@ -70,7 +70,8 @@ struct DeviceSchedule {
     Schedule sched;
     DevBuf<GemmTask> gemm;
     DevBuf<PotrfTask> potrf;
-    DevBuf<int32_t> relmap, gemm_tmap, solve_tmap;
+    DevBuf<int32_t> relmap, solve_tmap;
+    DevBuf<Schedule::TileEntry> gemm_tmap;
 };
 
 }  // namespace
@@ -102,7 +103,7 @@ struct mi355_factor_s {
     // instrumentation
     int profile = 0;
     double st_total = 0, st_gemm = 0, st_potrf = 0, st_asm = 0, st_solve = 0;
-    double st_ngemm = 0, st_npotrf = 0, st_tiles = 0;
+    double st_ngemm = 0, st_npotrf = 0, st_tiles = 0, st_nbig = 0, st_big = 0;
     EventTimer *timer = nullptr;   // events of the last profiled numeric call, collected lazily
 };
 
@@ -119,7 +120,7 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
     Schedule &S = D.sched;
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
-    HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_task.data(), S.gemm_tile_task.size(), F->stream));
+    HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_tab.data(), S.gemm_tile_tab.size(), F->stream));
     HIP_TRY(D.solve_tmap.upload(S.solve_tile_task.data(), S.solve_tile_task.size(), F->stream));
     HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
     if (S.relmap_size > 0) {
@@ -148,7 +149,7 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
 
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];   // 0 gemm 1 potrf 2 asm
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];   // 0 gemm64 1 potrf 2 asm 3 gemm128
     bool on = false;
     hipStream_t st = nullptr;
     void begin(int kind)
@@ -167,7 +168,7 @@ struct EventTimer {
     bool pending = false;
     void drop()
     {
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < 4; k++) {
             for (auto &p : ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
             ev[k].clear();
         }
@@ -219,7 +220,8 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
         } else {
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
-            tm.begin(0);
+            const int tk = (st.big && !cplx) ? 3 : 0;
+            tm.begin(tk);
             if (cplx)
                 hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
@@ -230,8 +232,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             else
                 hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
-            tm.end(0);
+            tm.end(tk);
             F->st_ngemm += 1;
+            if (tk == 3) F->st_nbig += 1;
             F->st_tiles += (double)st.ntiles;
         }
         HIP_TRY(hipGetLastError());
@@ -393,7 +396,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
     const Symbolic &S = F->sym;
     F->numeric_ok = false;
-    F->st_ngemm = F->st_npotrf = F->st_tiles = 0;
+    F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
     if (S.n == 0 || S.nsuper == 0) {
         F->minor = S.n; F->numeric_ok = true;
         if (minor) *minor = S.n;
@@ -521,7 +524,7 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     if (S.nsuper == 0) return MI355_OK;
     if (!F->timer) F->timer = new EventTimer;
     EventTimer &tm = *F->timer;
-    if (phase == 0) { tm.drop(); F->st_ngemm = F->st_npotrf = F->st_tiles = 0; }
+    if (phase == 0) { tm.drop(); F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0; }
     tm.on = F->profile != 0;
     tm.st = F->stream;
     hipEvent_t e0, e1;
@@ -681,6 +684,8 @@ int mi355_set_tuning(int key, int value)
     else if (key == 1) tuning().big_min_n = value;
     else if (key == 2) tuning().ob = value;
     else if (key == 3) tuning().mfma444 = value;
+    else if (key == 4) tuning().supertile = value;
+    else if (key == 5) tuning().xcd_deal = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -707,9 +712,17 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     DevBuf<GemmTask> dt;
     HIP_TRY(dt.upload(&t, 1, 0));
     const int64_t ntiles = gemm_tiles(M, N, t.mode, kernel ? BTILE : TILE);
-    DevBuf<int32_t> dmap;
-    HIP_TRY(dmap.alloc((size_t)ntiles));
-    HIP_TRY(hipMemset(dmap.p, 0, (size_t)ntiles * sizeof(int32_t)));
+    std::vector<Schedule::TileEntry> tab;
+    {
+        // same table builder as the factorization (super-tiles, XCD chunks): a one-task step
+        std::vector<Schedule::TileEntry> seq;
+        append_tiles(seq, 0, t, kernel ? BTILE : TILE);
+        deal_tiles(seq, tab);
+        const int64_t n = (int64_t)tab.size();
+        if (n != ntiles) return fail(MI355_INVALID, "tile table size mismatch");
+    }
+    DevBuf<Schedule::TileEntry> dmap;
+    HIP_TRY(dmap.upload(tab.data(), tab.size(), 0));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -769,7 +782,8 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
     const Schedule &S = F->full.sched;
     if (F->timer && F->timer->pending) {
         (void)hipSetDevice(F->device);
-        F->st_gemm = F->timer->collect(0); F->st_potrf = F->timer->collect(1); F->st_asm = F->timer->collect(2);
+        F->st_big = F->timer->collect(3);
+        F->st_gemm = F->timer->collect(0) + F->st_big; F->st_potrf = F->timer->collect(1); F->st_asm = F->timer->collect(2);
         F->timer->pending = false;
     }
     out[0] = F->st_total; out[1] = F->st_gemm; out[2] = F->st_ngemm; out[3] = F->st_potrf;
@@ -777,6 +791,8 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
     out[8] = S.bytes_assembly; out[9] = (double)S.pairs.size(); out[10] = (double)S.nlevels;
     out[11] = (double)S.relmap_size; out[12] = (double)S.dinv_size; out[13] = F->st_solve;
     out[14] = F->st_tiles; out[15] = 0;
+    out[16] = F->st_big; out[17] = F->st_nbig; out[18] = S.flops_big; out[19] = S.flops_small;
+    out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[22] = 0; out[23] = 0;
     return MI355_OK;
 }
 

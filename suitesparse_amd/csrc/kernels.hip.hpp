@@ -122,7 +122,7 @@ constexpr int G64_KS = 16;          // K per LDS stage
 constexpr int G64_LD = 80;          // padded row stride (doubles): 640 B, lanes 16..31 land on banks 32..63
 
 __global__ __launch_bounds__(256) void k_gemm64(
-    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double As[G64_KS][G64_LD];
@@ -131,12 +131,10 @@ __global__ __launch_bounds__(256) void k_gemm64(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    const GemmTask t = tasks[tile_task[bid]];
+    const Schedule::TileEntry te = tile_tab[bid];
+    const GemmTask t = tasks[te.task];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
-    const int MT = (M + TILE - 1) / TILE, NT = (N + TILE - 1) / TILE;
-    int tm, tn;
-    tile_coords(bid - t.tile0, MT, NT, mode, tm, tn);
-    if (tm >= MT || tn >= NT) return;           // host guarantees this never happens
+    const int tm = (int)(te.tmtn & 0xffffu), tn = (int)(te.tmtn >> 16);
     const int m0 = tm * TILE, n0 = tn * TILE;
 
     const double *__restrict__ A = Lx + t.a_off;
@@ -254,7 +252,7 @@ constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row =>
 // product whose result has m along lane%16 and n along lane/16 -- the same store pattern as before.
 template <bool MFMA444>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
-    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double As[2][G128_KS][G128_LD];
@@ -263,12 +261,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    const GemmTask t = tasks[tile_task[bid]];
+    const Schedule::TileEntry te = tile_tab[bid];
+    const GemmTask t = tasks[te.task];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
-    const int MT = (M + BTILE - 1) / BTILE, NT = (N + BTILE - 1) / BTILE;
-    int tm, tn;
-    tile_coords(bid - t.tile0, MT, NT, mode, tm, tn);
-    if (tm >= MT || tn >= NT) return;
+    const int tm = (int)(te.tmtn & 0xffffu), tn = (int)(te.tmtn >> 16);
     const int m0 = tm * BTILE, n0 = tn * BTILE;
 
     const double *__restrict__ A = Lx + t.a_off;

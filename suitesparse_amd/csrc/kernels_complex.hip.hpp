@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_assemble_c(
 // k_gemm64c: complex C = A * B^H, 64x64 tile, 4 waves (2x2), 2x2 MFMA blocks x {re,im}
 //------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gemm64c(
-    const GemmTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, double *__restrict__ Lx,
+    const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
 {
     __shared__ double Ar[G64_KS][G64_LD], Ai_[G64_KS][G64_LD];
@@ -59,12 +59,10 @@ __global__ __launch_bounds__(256) void k_gemm64c(
 
     const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
-    const GemmTask t = tasks[tile_task[bid]];
+    const Schedule::TileEntry te = tile_tab[bid];
+    const GemmTask t = tasks[te.task];
     const int M = t.M, N = t.N, K = t.K, mode = t.mode;
-    const int MT = (M + TILE - 1) / TILE, NT = (N + TILE - 1) / TILE;
-    int tm, tn;
-    tile_coords(bid - t.tile0, MT, NT, mode, tm, tn);
-    if (tm >= MT || tn >= NT) return;
+    const int tm = (int)(te.tmtn & 0xffffu), tn = (int)(te.tmtn >> 16);
     const int m0 = tm * TILE, n0 = tn * TILE;
 
     const v2d *__restrict__ A = (const v2d *)Lx + t.a_off;

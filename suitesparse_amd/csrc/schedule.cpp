@@ -80,6 +80,47 @@ GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int
     return t;
 }
 
+}  // namespace
+
+// tiles of one task in super-tile order: G x G groups of tiles (G = tuning().supertile; 1 = plain
+// row-major over the lower trapezoid), row-major over the groups
+void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile)
+{
+    const int64_t G = std::max(1, tuning().supertile);
+    const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
+    const bool lower = (t.mode != GEMM_OVERWRITE) && (MT >= NT);
+    for (int64_t I = 0; I < MT; I += G)
+        for (int64_t J = 0; J < NT && (!lower || J <= I + G - 1); J += G)
+            for (int64_t tm = I; tm < std::min(I + G, MT); tm++)
+                for (int64_t tn = J; tn < std::min(J + G, NT); tn++) {
+                    if (lower && tn > tm) continue;
+                    Schedule::TileEntry e;
+                    e.task = task;
+                    e.tmtn = (uint32_t)tm | ((uint32_t)tn << 16);
+                    seq.push_back(e);
+                }
+}
+
+// workgroup b runs entry u(b) of the sequence.  With tuning().xcd_deal the sequence is dealt to the
+// 8 XCDs in contiguous chunks (workgroups go round-robin over the XCDs, so XCD x sees a contiguous
+// eighth of the sequence and the operand panels of neighbouring tiles share its L2).
+void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab)
+{
+    const int64_t n = (int64_t)seq.size(), q = n / 8, r = n % 8;
+    const size_t base = tab.size();
+    tab.resize(base + (size_t)n);
+    for (int64_t b = 0; b < n; b++) {
+        int64_t u = b;
+        if (tuning().xcd_deal) {
+            const int64_t x = b % 8, j = b / 8;
+            u = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        }
+        tab[base + (size_t)b] = seq[(size_t)u];
+    }
+}
+
+namespace {
+
 // append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
 // kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
 // tile0 prefix sums
@@ -91,7 +132,8 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_
         Step st;
         st.kind = STEP_GEMM; st.level = level; st.big = big; st.pad = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
-        st.tmap_off = (int64_t)out.gemm_tile_task.size();
+        st.tmap_off = (int64_t)out.gemm_tile_tab.size();
+        std::vector<Schedule::TileEntry> seq;
         for (auto &t : tasks) {
             const int is_big = (!no_big && t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
             if (is_big != big) continue;
@@ -101,14 +143,55 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_
             t.tile0 = st.ntiles;
             st.ntiles += nt;
             out.gemm.push_back(t);
-            out.gemm_tile_task.insert(out.gemm_tile_task.end(), (size_t)nt, (int32_t)st.count);
+            append_tiles(seq, (int32_t)st.count, t, big ? BTILE : TILE);
+            {
+                const double Mm = t.M, Nn = t.N, Kk = t.K;
+                const double fl = (t.mode == GEMM_OVERWRITE) ? Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
+                if (big) { out.flops_big += fl; out.tiles_big += nt; } else { out.flops_small += fl; out.tiles_small += nt; }
+            }
             st.count++;
         }
-        if (st.count > 0) out.steps.push_back(st);
+        if (st.count > 0) {
+            deal_tiles(seq, out.gemm_tile_tab);
+            out.steps.push_back(st);
+        }
     }
 }
 
 }  // namespace
+
+bool check_tile_table(const Schedule &sc, const Step &st)
+{
+    if (st.kind != STEP_GEMM) return true;
+    std::vector<std::vector<uint8_t>> seen((size_t)st.count);
+    for (int64_t i = 0; i < st.count; i++) {
+        const GemmTask &t = sc.gemm[(size_t)(st.first + i)];
+        const int tile = t.big ? BTILE : TILE;
+        const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
+        seen[(size_t)i].assign((size_t)(MT * NT), 0);
+    }
+    int64_t count = 0;
+    for (int64_t b = 0; b < st.ntiles; b++) {
+        const Schedule::TileEntry e = sc.gemm_tile_tab[(size_t)(st.tmap_off + b)];
+        if (e.task < 0 || e.task >= st.count) return false;
+        const GemmTask &t = sc.gemm[(size_t)(st.first + e.task)];
+        const int tile = t.big ? BTILE : TILE;
+        const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
+        const int64_t tm = e.tmtn & 0xffff, tn = e.tmtn >> 16;
+        if (tm >= MT || tn >= NT) return false;
+        if (t.mode != GEMM_OVERWRITE && MT >= NT && tn > tm) return false;
+        uint8_t &f = seen[(size_t)e.task][(size_t)(tm * NT + tn)];
+        if (f) return false;
+        f = 1;
+        count++;
+    }
+    int64_t want = 0;
+    for (int64_t i = 0; i < st.count; i++) {
+        const GemmTask &t = sc.gemm[(size_t)(st.first + i)];
+        want += gemm_tiles(t.M, t.N, t.mode, t.big ? BTILE : TILE);
+    }
+    return count == want && want == st.ntiles;
+}
 
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
                     const int8_t *mask)

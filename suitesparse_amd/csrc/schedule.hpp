@@ -96,9 +96,15 @@ struct Schedule {
     std::vector<GemmTask> gemm;
     std::vector<UpdatePair> pairs;
     std::vector<Step> steps;
-    // tile -> task (index relative to the step's first task), one int32 per workgroup: a workgroup
-    // finds its task with ONE load instead of a binary search of dependent loads
-    std::vector<int32_t> gemm_tile_task, solve_tile_task;
+    // One entry per GEMM workgroup, indexed by blockIdx.x inside its launch: the task (index relative
+    // to the step's first task) and the tile coordinates.  The host chooses the order: tiles of a task
+    // are grouped in 8x8 super-tiles (64 tiles that share 8 A-panels and 8 B-panels), and the sequence
+    // is dealt to the 8 XCDs in contiguous chunks (blocks b and b+8 share an XCD and its L2), so the
+    // ~64 workgroups resident on one XCD at a time re-read each other's operand panels from L2.
+    struct TileEntry { int32_t task; uint32_t tmtn; };      // tm = tmtn & 0xffff, tn = tmtn >> 16
+    std::vector<TileEntry> gemm_tile_tab;
+    // solve row tiles: tile -> task (relative), one load instead of a binary search
+    std::vector<int32_t> solve_tile_task;
     int64_t relmap_size = 0;            // total relative-map entries (sum of ndrow2 over pairs)
     int64_t dinv_size = 0;              // total entries of the block inverses (sum nb^2)
     // truncation (not-positive-definite repeat, worker :1084-1146); s_limit == nsuper: none
@@ -106,6 +112,8 @@ struct Schedule {
     int64_t nscol2_limit = 0;
     // statistics
     double flops_update = 0, flops_panel = 0;
+    double flops_big = 0, flops_small = 0;  // useful flops of the GEMM tasks routed to k_gemm128 / k_gemm64
+    int64_t tiles_big = 0, tiles_small = 0;
     double bytes_assembly = 0;          // sum over pairs of ndrow1*ndrow2*8
     int64_t max_nscol = 0, max_nsrow = 0;
 };
@@ -124,8 +132,13 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     const int8_t *mask = nullptr);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; int mfma444 = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; int mfma444 = 0; int supertile = 8; int xcd_deal = 0; };
 Tuning &tuning();
+void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile);
+void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);
+
+// true if the table of step st lists every valid tile of every task of the step exactly once
+bool check_tile_table(const Schedule &sc, const Step &st);
 
 // number of TILE-tiles of one task
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile);

@@ -119,7 +119,8 @@ def set_tuning(key, value):
 
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
              "flops_update", "flops_panel", "bytes_assembly", "npairs", "nlevels", "relmap_entries",
-             "dinv_entries", "solve_ms", "gemm_tiles", "reserved"]
+             "dinv_entries", "solve_ms", "gemm_tiles", "reserved", "gemm128_ms", "gemm128_launches",
+             "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "reserved2", "reserved3"]
 
 
 class SupernodalFactor:
@@ -266,7 +267,7 @@ class SupernodalFactor:
         _check(lib().mi355_factor_set_profile(self._h, int(bool(on))))
 
     def stats(self):
-        out = np.zeros(16)
+        out = np.zeros(24)
         _check(lib().mi355_factor_get_stats(self._h, out))
         return dict(zip(STAT_KEYS, out.tolist()))
 

@@ -98,7 +98,7 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                         } else T[m + (int64_t)n * t.ldc] = v;
                     }
             }
-            if (tiles != st.ntiles) info[S.nsuper + 1] = -1;
+            if (tiles != st.ntiles || !check_tile_table(sc, st)) info[S.nsuper + 1] = -1;
         }
     }
 }
