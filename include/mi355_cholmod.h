@@ -160,12 +160,12 @@ int mi355_factor_get_stats(mi355_factor *handle, double *out24);
 int mi355_debug_mfma_f64_rate(int device, double *out3);
 
 /* Rate of ONE trailing-update task (lower trapezoid M x N, depth K) on random data with kernel 0
- * (k_gemm64), 1 (k_gemm128 on the 4x4x4 FP64 MFMA) or 2 (k_gemm128 on the 16x16x4 FP64 MFMA);
- * kernel micro-benchmark for profiles/, no reference counterpart. */
+ * (k_gemm64) or 1 (k_gemm128); kernel micro-benchmark for profiles/, no reference counterpart. */
 int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters, double *tflops);
 
 /* key 0: minimum M, key 1: minimum N of a task routed to the 128x128-tile kernel, key 2: outer
- * block width (affect factors created afterwards); key 3: 1 = 4x4x4 MFMA in k_gemm128, 0 = 16x16x4. */
+ * block width (affect factors created afterwards); key 3: retired; key 4: super-tile edge of the tile
+ * order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -226,9 +226,10 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                 hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             else if (st.big)
-                hipLaunchKernelGGL(tuning().mfma444 ? k_gemm128<true> : k_gemm128<false>, dim3((unsigned)st.ntiles),
+                hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles),
                                    dim3(256), 0, F->stream,
-                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
+                                   st.ntiles >= 1536 ? tuning().stagger : 0, (unsigned long long *)nullptr);
             else
                 hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
@@ -683,9 +684,10 @@ int mi355_set_tuning(int key, int value)
     if (key == 0) tuning().big_min_m = value;
     else if (key == 1) tuning().big_min_n = value;
     else if (key == 2) tuning().ob = value;
-    else if (key == 3) tuning().mfma444 = value;
+    else if (key == 3) (void)value;                 // retired (4x4x4 MFMA variant)
     else if (key == 4) tuning().supertile = value;
     else if (key == 5) tuning().xcd_deal = value;
+    else if (key == 6) tuning().stagger = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -723,15 +725,17 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     }
     DevBuf<Schedule::TileEntry> dmap;
     HIP_TRY(dmap.upload(tab.data(), tab.size(), 0));
+    DevBuf<unsigned long long> dstamps;                 // MI355_GEMM_STAMPS=file: per-tile phase clocks of the last launch
+    const char *stamp_file = getenv("MI355_GEMM_STAMPS");
+    if (stamp_file && kernel >= 1) HIP_TRY(dstamps.alloc((size_t)ntiles * 4));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int it = -2; it < iters; it++) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
-        if (kernel == 1)
-            hipLaunchKernelGGL(k_gemm128<true>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
-        else if (kernel == 2)
-            hipLaunchKernelGGL(k_gemm128<false>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
+        if (kernel >= 1)
+            hipLaunchKernelGGL(k_gemm128, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr,
+                               ntiles >= 1536 ? tuning().stagger : 0, dstamps.p);
         else
             hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
     }
@@ -743,6 +747,16 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     const double flops = 2.0 * K * ((double)N * (N + 1) / 2 + (double)(M - N) * N) * iters;
     *tflops = flops / (ms * 1e-3) * 1e-12;
+    if (dstamps.p) {
+        std::vector<unsigned long long> hs((size_t)ntiles * 4);
+        HIP_TRY(hipMemcpy(hs.data(), dstamps.p, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(stamp_file, "w")) {
+            for (int64_t b = 0; b < ntiles; b++)
+                fprintf(f, "%lld %u %u %llu %llu %llu %llu\n", (long long)b, tab[(size_t)b].tmtn & 0xffffu, tab[(size_t)b].tmtn >> 16,
+                        hs[4 * b], hs[4 * b + 1], hs[4 * b + 2], hs[4 * b + 3]);
+            fclose(f);
+        }
+    }
     return MI355_OK;
 }
 

@@ -11,6 +11,7 @@
 //                   (worker :1023,:1175; t_cholmod_gpu.c:784-1135,1151-1393)
 // k_potrf64         dpotrf of one <=64 diagonal block + its inverse            latency
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "schedule.hpp"
@@ -234,27 +235,29 @@ __global__ __launch_bounds__(256) void k_gemm64(
 //------------------------------------------------------------------------------
 // k_gemm128: the large-task variant.  128x128 tile per 256-thread workgroup, 4 waves as
 // 2x2, each wave 64x64 = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs), K staged 16
-// at a time through a DOUBLE-BUFFERED LDS image: the global loads of stage k+1 are issued
-// into registers before the 64 MFMAs of stage k and written to the other buffer after
-// them, one barrier per stage.  Same operand-role swap and epilogues as k_gemm64.
+// at a time through a double-buffered LDS image.  Same operand-role swap and epilogues as
+// k_gemm64.
+//
+// The FP64 MFMA pipe runs one 16x16x4 instruction per 64 cycles per SIMD
+// (profiles/r01_mfma_f64_probe3.txt: 72-78 TFLOP/s chip-wide from registers), and the two
+// workgroups of a CU fall into lock-step, so whatever a wave does OUTSIDE its MFMA stream
+// is lost pipe time (profiles/r01_pmc_sq_k_gemm128_before.txt: pipe 69 % busy with the
+// loads, LDS writes and barrier clustered between the MFMA runs).  The staging is therefore
+// spread through the MFMA stream: one register set, the slice loaded during stage s
+// (for stage s+2) is written to LDS during stage s+1 right before the register is
+// re-loaded -- a full stage of flight time per load, two loads + two LDS writes behind
+// every 8 MFMAs, and a loop body without branches (edge rows are clamped: their products
+// only reach C entries that are never stored; the K tail is zeroed on the way into LDS).
 //------------------------------------------------------------------------------
 constexpr int G128_KS = 16;
 constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row => conflict-free ds_read_b64
 
-// MFMA444 = true: the inner product runs on v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64.
-// Measured on MI355X (profiles/r01_mfma_f64_probe.txt): one wave issues a 16x16x4 f64 MFMA only every
-// ~140 cycles (47 TFLOP/s chip-wide at best, 4 waves/SIMD) while the 4-block 4x4x4 form issues every
-// 17.5 cycles (64 TFLOP/s with ONE wave per SIMD) -- the vendor FP64-matrix peak is a 4x4x4 number.
-// Lane layout of the 4x4x4 form (probed, tools/probes/mfma444_layout.hip): lane l = 16k + 4b + x feeds
-// A_b[x][k] and B_b[k][x]; D_b[i][j] lands in lane 16i + 4b + j.  Feeding the B-matrix rows
-// (n = 4rn + x, the same for all four blocks) as the first operand and the A-matrix rows
-// (m = 16rm + 4b + x = 16rm + lane%16) as the second makes one instruction a (16 m) x (4 n) x (4 k)
-// product whose result has m along lane%16 and n along lane/16 -- the same store pattern as before.
-template <bool MFMA444>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
     const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
-    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap)
+    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap, int stagger,
+    unsigned long long *__restrict__ stamps)       // debug builds of the micro-benchmark only: 4 clock stamps per tile
 {
+    const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     __shared__ double As[2][G128_KS][G128_LD];
     __shared__ double Bs[2][G128_KS][G128_LD];
     __shared__ int rmM[BTILE], rmN[BTILE];
@@ -276,87 +279,134 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
         else { int j = tid - BTILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
     }
 
+    // All tiles of a launch take about the same time, so without help every workgroup of the chip reaches
+    // its read-modify-write epilogue at the same moment (HBM saturated, MFMA pipes idle) and then its main
+    // loop at the same moment (HBM idle).  The workgroups of the first round (two per CU) therefore start
+    // with a pseudo-random delay of up to one tile time, which spreads the phases for the whole launch.
+    if (stagger > 0 && bid < 512) {
+        const unsigned h = ((unsigned)bid * 2654435761u) >> 22;                   // 0..1023
+        const int units = (int)(((int64_t)((K + G128_KS - 1) / G128_KS) * stagger * h) >> 10);   // of 64*127 cycles
+        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(127);
+    }
+
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
     // a diagonal tile of a lower-trapezoid task needs nothing from its strictly upper 64x64 quadrant
     const bool skip_mma = (mode != GEMM_OVERWRITE) && (m0 == n0) && (wm < wn);
 
-    // 64 accumulator doubles per lane either way: 16x16x4: acc[ni][mi][r] ; 4x4x4: c[rn = 4*ni + r][rm = mi]
-    // -- in both cases element (ni, mi, r) is C[m = 16*mi + lane%16][n = 16*ni + 4*r + lane/16] of the wave tile
+    // acc[ni][mi][r] is C[m = 16*mi + lane%16][n = 16*ni + 4*r + lane/16] of the wave's 64x64 tile
     v4d acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    const int lrow = tid & 127, lk = tid >> 7;   // each thread stages 8 k-values of one A row and one B row
-    const bool arow_ok = (m0 + lrow) < M, brow_ok = (n0 + lrow) < N;
-    const double *Ap = A + (m0 + lrow);
-    const double *Bp = B + (n0 + lrow);
+    // each thread stages 8 k-values (lk, lk+2, ..) of one A row and one B row; lk is wave-uniform
+    const int lrow = tid & 127, lk = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const double *Ap = A + min(m0 + lrow, M - 1);
+    const double *Bp = B + min(n0 + lrow, N - 1);
     double ra[8], rb[8];
 
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int kk = k0 + lk + 2 * q;
-            const bool kok = kk < K;
-            ra[q] = (arow_ok && kok) ? Ap[(int64_t)kk * lda] : 0.0;
-            rb[q] = (brow_ok && kok) ? Bp[(int64_t)kk * ldb] : 0.0;
-        }
+    auto gload1 = [&](int q, int k0) {
+        const int kk = min(k0 + lk + 2 * q, K - 1);
+        ra[q] = Ap[(int64_t)kk * lda];
+        rb[q] = Bp[(int64_t)kk * ldb];
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            As[buf][lk + 2 * q][lrow] = ra[q];
-            Bs[buf][lk + 2 * q][lrow] = rb[q];
-        }
+    auto lstore1 = [&](int q, int k0, int buf) {
+        const bool kok = (k0 + lk + 2 * q) < K;
+        As[buf][lk + 2 * q][lrow] = kok ? ra[q] : 0.0;
+        Bs[buf][lk + 2 * q][lrow] = kok ? rb[q] : 0.0;
     };
 
-    gload(0);
-    lstore(0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) gload1(q, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { lstore1(q, 0, 0); gload1(q, G128_KS); }
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += G128_KS) {
-        const bool more = (k0 + G128_KS) < K;
-        if (more) gload(k0 + G128_KS);
-        if (!skip_mma) {
+
+    // operand registers, two sets: step ks computes from set ks&1 while set (ks+1)&1 is being read
+    double fa[2][4], fb[2][4];
+    auto fread = [&](int set, int buf, int ks, int h) {          // h = 0..3: one ds_read2_b64 each
+        const int kk = ks * 4 + l4;
+        if (h < 2) {
+            fa[set][2 * h] = As[buf][kk][wm * 64 + (2 * h) * 16 + l15];
+            fa[set][2 * h + 1] = As[buf][kk][wm * 64 + (2 * h + 1) * 16 + l15];
+        } else {
+            fb[set][2 * h - 4] = Bs[buf][kk][wn * 64 + (2 * h - 4) * 16 + l15];
+            fb[set][2 * h - 3] = Bs[buf][kk][wn * 64 + (2 * h - 3) * 16 + l15];
+        }
+    };
+    // staging piece g (0..3) of step ks: element q = 2ks + g/2, matrix A (g even) or B (g odd):
+    // stage s+1's value goes to the other LDS buffer, then the register is re-loaded for stage s+2
+    auto stage_write = [&](int ks, int g, int k0, int buf) {
+        const int q = 2 * ks + (g >> 1);
+        const bool kok = (k0 + G128_KS + lk + 2 * q) < K;
+        if ((g & 1) == 0) As[buf ^ 1][lk + 2 * q][lrow] = kok ? ra[q] : 0.0;
+        else Bs[buf ^ 1][lk + 2 * q][lrow] = kok ? rb[q] : 0.0;
+    };
+    auto stage_load = [&](int ks, int g, int k0) {
+        const int q = 2 * ks + (g >> 1);
+        const int kk = min(k0 + 2 * G128_KS + lk + 2 * q, K - 1);
+        if ((g & 1) == 0) ra[q] = Ap[(int64_t)kk * lda];
+        else rb[q] = Bp[(int64_t)kk * ldb];
+    };
+
+    const unsigned long long st1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto mainloop = [&](auto with_mma) {
+        constexpr bool MMA = decltype(with_mma)::value;
+        int buf = 0;
+        if constexpr (MMA) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) fread(0, 0, 0, h);
+        }
+        for (int k0 = 0; k0 < K; k0 += G128_KS) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                const int kk = ks * 4 + l4;
-                if constexpr (MFMA444) {
-                    double a[4], b[16];
+                const int set = ks & 1;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
-#pragma unroll
-                    for (int j = 0; j < 16; j++) b[j] = Bs[buf][kk][wn * 64 + j * 4 + (lane & 3)];
-#pragma unroll
-                    for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-#pragma unroll
-                            for (int mi = 0; mi < 4; mi++)
-                                acc[ni][mi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(b[4 * ni + r], a[mi], acc[ni][mi][r], 0, 0, 0);
-                } else {
-                    double a[4], b[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        a[i] = As[buf][kk][wm * 64 + i * 16 + l15];
-                        b[i] = Bs[buf][kk][wn * 64 + i * 16 + l15];
+                for (int g = 0; g < 4; g++) {
+                    // the hand-placed issue order: 2 MFMAs | select + LDS write | MFMA | address + global load |
+                    // MFMA | operand read for the next step.  The last 4 MFMAs of a stage are issued AFTER the
+                    // barrier, behind the first operand reads of the next stage, whose latency they cover.
+                    const bool tail = (ks == 3 && g == 3);
+                    if (MMA && !tail) {
+                        acc[g][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][g], fa[set][0], acc[g][0], 0, 0, 0);
+                        acc[g][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][g], fa[set][1], acc[g][1], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                        for (int mi = 0; mi < 4; mi++)
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_write(ks, g, k0, buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MMA && !tail) acc[g][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][g], fa[set][2], acc[g][2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_load(ks, g, k0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MMA && !tail) acc[g][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][g], fa[set][3], acc[g][3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MMA && ks < 3) fread(set ^ 1, buf, ks + 1, g);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            __syncthreads();
+            if constexpr (MMA) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 4; h++) fread(0, buf ^ 1, 0, h);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+                    acc[3][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[1][3], fa[1][mi], acc[3][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
         }
-        if (more) lstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    };
+    if (skip_mma) {
+        mainloop(std::false_type{});
+        return;
     }
-    if (skip_mma) return;
+    mainloop(std::true_type{});
+    const unsigned long long st2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const int64_t ldc = t.ldc;
     double *__restrict__ C = Lx + t.c_off;
@@ -369,15 +419,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
             double cv[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int n = n0 + wn * 64 + (q >> 2) * 16 + (MFMA444 ? (4 * (q & 3) + l4) : (l4 + 4 * (q & 3)));
+                const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
                 const bool ok = (m < M) && (n < N) && (m >= n);
                 cv[q] = C[ok ? (m + (int64_t)n * ldc) : 0];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int n = n0 + wn * 64 + (q >> 2) * 16 + (MFMA444 ? (4 * (q & 3) + l4) : (l4 + 4 * (q & 3)));
+                const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
                 if ((m < M) && (n < N) && (m >= n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 2][mi][q & 3];
             }
+        }
+        if (stamps && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            stamps[4 * bid] = st0; stamps[4 * bid + 1] = st1; stamps[4 * bid + 2] = st2;
+            stamps[4 * bid + 3] = __builtin_amdgcn_s_memtime();
         }
         return;
     }
@@ -389,8 +444,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
             const int m = m0 + ml;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                // 16x16x4: D row (n) = lane/16 + 4r ; 4x4x4: n = 4*(4ni + r) + lane/16
-                const int nl = wn * 64 + ni * 16 + (MFMA444 ? (4 * r + l4) : (l4 + 4 * r));
+                const int nl = wn * 64 + ni * 16 + l4 + 4 * r;        // D row (n) = lane/16 + 4r
                 const int n = n0 + nl;
                 if (m < M && n < N) {
                     const double v = acc[ni][mi][r];
