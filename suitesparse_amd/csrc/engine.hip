@@ -208,8 +208,15 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
         HIP_TRY(hipGetLastError());
     }
     tm.end(2);
+    // MI355_STEP_LOG=file: one line per launch (synchronising; analysis runs only)
+    FILE *steplog = nullptr;
+    if (const char *fn = getenv("MI355_STEP_LOG")) steplog = fopen(fn, "w");
+    hipEvent_t le0 = nullptr, le1 = nullptr;
+    if (steplog) { (void)hipEventCreate(&le0); (void)hipEventCreate(&le1); }
+    struct LogCloser { FILE *&f; hipEvent_t &a, &b; ~LogCloser() { if (f) { fclose(f); (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } } closer{steplog, le0, le1};
     for (const Step &st : D.sched.steps) {
         if (st.count <= 0) continue;
+        if (steplog) (void)hipEventRecord(le0, F->stream);
         if (st.kind == STEP_POTRF) {
             if (st.count > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many POTRF tasks in one step");
             tm.begin(1);
@@ -239,6 +246,27 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             F->st_tiles += (double)st.ntiles;
         }
         HIP_TRY(hipGetLastError());
+        if (steplog) {
+            (void)hipEventRecord(le1, F->stream);
+            (void)hipEventSynchronize(le1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, le0, le1);
+            if (st.kind == STEP_POTRF) {
+                fprintf(steplog, "potrf level %d count %lld ms %.4f\n", st.level, (long long)st.count, ms);
+            } else {
+                double fl = 0; int kmin = 1 << 30, kmax = 0; int64_t mmax = 0, nmax = 0;
+                for (int64_t i = 0; i < st.count; i++) {
+                    const GemmTask &t = D.sched.gemm[(size_t)(st.first + i)];
+                    const double Mm = t.M, Nn = t.N, Kk = t.K;
+                    fl += (t.mode == GEMM_OVERWRITE) ? 2 * Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
+                    kmin = std::min(kmin, t.K); kmax = std::max(kmax, t.K);
+                    mmax = std::max<int64_t>(mmax, t.M); nmax = std::max<int64_t>(nmax, t.N);
+                }
+                fprintf(steplog, "gemm level %d big %d mode %d count %lld ntiles %lld flops %.6g kmin %d kmax %d mmax %lld nmax %lld ms %.4f\n",
+                        st.level, st.big, D.sched.gemm[(size_t)st.first].mode, (long long)st.count, (long long)st.ntiles, fl,
+                        kmin, kmax, (long long)mmax, (long long)nmax, ms);
+            }
+        }
     }
     return MI355_OK;
 }

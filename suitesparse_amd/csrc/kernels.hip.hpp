@@ -464,12 +464,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 // its inverse (used as the TRSM operand and by the solves).  One workgroup per task.
 // info[s] receives the 1-based column (inside s) of the first pivot that is <= 0 or
 // NaN -- LAPACK dpotrf's INFO, worker :1023-1027,:1084-1095.
+//
+// The block is on the critical path of every panel step, so the kernel is built for
+// latency: right-looking over four 16-column blocks; the 16x16 diagonal block and its
+// inverse are computed by ONE wave entirely in registers (lane = row, pivots and
+// multipliers move between lanes with v_readlane -- no LDS traffic, no barrier inside
+// the 16 column steps, one reciprocal square root per column instead of a square root
+// and a division), the 16-wide TRSM and the trailing update are 16x16x4 FP64 MFMA
+// products on LDS operands (3 barriers per 16 columns instead of 3 per column), and the
+// 64x64 inverse is assembled from the 16x16 ones by MFMA block products.
 //------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_bcast(double v, int srclane)      // srclane: compile-time constant
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_potrf64(
     const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
     double *__restrict__ Dinv, int *__restrict__ info)
 {
-    __shared__ double Ls[NB][NB + 1];
+    __shared__ double Ls[NB][NB + 1];       // the block, factorized in place (row i, column j)
+    __shared__ double Vs[NB][NB + 1];       // its inverse
     const PotrfTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const int nb = t.nb;
@@ -481,25 +498,80 @@ __global__ __launch_bounds__(256) void k_potrf64(
         double v = (i == j) ? 1.0 : 0.0;                     // identity padding
         if (i < nb && j < nb) v = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
         Ls[i][j] = v;
+        Vs[i][j] = 0.0;
     }
     __syncthreads();
 
-    bool failed = false;
-    for (int j = 0; j < nb; j++) {
-        const double d = Ls[j][j];
-        if (!(d > 0.0) && !failed) {
-            failed = true;
-            if (tid == 0 && info[t.s] == 0) info[t.s] = t.col0 + j + 1;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    bool failed = false;                                      // wave 0 only
+#pragma unroll 1
+    for (int jb = 0; jb < 4; jb++) {
+        const int c0 = 16 * jb;
+        if (wave == 0) {
+            // lane r (mod 16) holds row r of the diagonal block; entries right of the diagonal are never
+            // consumed (they collect harmless junk) and are written back as zeros
+            double a[16], rs[16], w[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a[k] = Ls[c0 + l15][c0 + k];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const double d = lane_bcast(a[j], j);
+                if (!(d > 0.0) && !failed) {
+                    failed = true;
+                    if (lane == 0 && info[t.s] == 0) info[t.s] = t.col0 + c0 + j + 1;
+                }
+                const double r = 1.0 / sqrt(d);
+                rs[j] = r;
+                a[j] = (l15 == j) ? d * r : a[j] * r;
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) a[k] -= a[j] * lane_bcast(a[j], k);
+                __builtin_amdgcn_sched_barrier(0);            // keeps the broadcast values (SGPRs) short-lived
+            }
+            // W = inv(L_jj): lane c holds column c, w[i] = (delta_ic - sum_{k<i} L[i][k] w[k]) / L[i][i]
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double acc = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) acc -= lane_bcast(a[k], i) * w[k];
+                w[i] = acc * rs[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    Ls[c0 + lane][c0 + k] = (k <= lane) ? a[k] : 0.0;
+                    Vs[c0 + k][c0 + lane] = w[k];
+                }
+            }
         }
-        const double ljj = sqrt(d);
         __syncthreads();
-        if (tid == 0) Ls[j][j] = ljj;
-        for (int i = j + 1 + tid; i < nb; i += 256) Ls[i][j] /= ljj;
+        // TRSM: X_ib = A(ib,jb) * W^T for the block rows below (one per wave)
+        {
+            const int ib = jb + 1 + wave;
+            if (ib < 4) {
+                v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * ib + l15][c0 + 4 * q + l4], Vs[c0 + l15][c0 + 4 * q + l4], x, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ls[16 * ib + l4 + 4 * r][c0 + l15] = x[r];
+            }
+        }
         __syncthreads();
-        const int i = j + 1 + (tid & 63);
-        if (i < nb) {
-            const double lij = Ls[i][j];
-            for (int k = j + 1 + (tid >> 6); k <= i; k += 4) Ls[i][k] -= lij * Ls[k][j];
+        // trailing update: A(ib,kb) -= X_ib X_kb^T for jb < kb <= ib < 4, block pairs dealt to the waves
+        {
+            const int nrem = 3 - jb, npairs = nrem * (nrem + 1) / 2;
+            for (int p = wave; p < npairs; p += 4) {
+                int ib = 0, q = p;
+                while (q > ib) { q -= ib + 1; ib++; }          // p -> (ib, q): q <= ib
+                const int bi = jb + 1 + ib, bk = jb + 1 + q;
+                v4d c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int z = 0; z < 4; z++)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * bi + l15][c0 + 4 * z + l4], Ls[16 * bk + l15][c0 + 4 * z + l4], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ls[16 * bi + l4 + 4 * r][16 * bk + l15] -= c[r];
+            }
         }
         __syncthreads();
     }
@@ -509,32 +581,32 @@ __global__ __launch_bounds__(256) void k_potrf64(
         if (i < nb && j < nb && i >= j) A[i + (int64_t)j * lda] = Ls[i][j];
     }
 
-    // inverse of the (identity-padded) 64x64 lower-triangular block: lane c of wave 0
-    // solves L x = e_c by a fully unrolled column sweep held in registers
-    double x[NB];
-    if (tid < NB) {
-        const int c = tid;
+    // off-diagonal blocks of the inverse, by distance d from the diagonal:
+    // V(i,j) = -W_i * sum_{k=j}^{i-1} L(i,k) V(k,j); the sum's MFMA result registers are the B operand of W_i * (.)
 #pragma unroll
-        for (int i = 0; i < NB; i++) x[i] = (i == c) ? 1.0 : 0.0;
+    for (int d = 1; d < 4; d++) {
+        const int j = wave, i = wave + d;
+        if (i < 4) {
+            v4d tsum = {0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; k++) {
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const double xk = x[k] / Ls[k][k];
-            x[k] = xk;
+                for (int z = 0; z < 4; z++)
+                    tsum = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * i + l15][16 * k + 4 * z + l4], Vs[16 * k + 4 * z + l4][16 * j + l15], tsum, 0, 0, 0);
+            }
+            v4d v = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int i = k + 1; i < NB; i++) x[i] -= Ls[i][k] * xk;
+            for (int z = 0; z < 4; z++)
+                v = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[16 * i + l15][16 * i + 4 * z + l4], tsum[z], v, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Vs[16 * i + l4 + 4 * r][16 * j + l15] = -v[r];
         }
+        __syncthreads();
     }
-    __syncthreads();                                          // all reads of L done
-    if (tid < NB) {
-#pragma unroll
-        for (int i = 0; i < NB; i++) Ls[i][tid] = x[i];       // Ls := inv(L)
-    }
-    __syncthreads();
     if (t.dinv_off >= 0) {
         double *__restrict__ D = Dinv + t.dinv_off;
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx % nb, j = idx / nb;
-            D[idx] = (i >= j) ? Ls[i][j] : 0.0;               // column-major, ld = nb
+            D[idx] = (i >= j) ? Vs[i][j] : 0.0;               // column-major, ld = nb
         }
     }
 }

@@ -1,5 +1,8 @@
 set -e
-for t in "4=1,5=0" "4=1,5=1" "4=4,5=1" "4=8,5=0" "4=8,5=1" "4=2,5=1" "4=16,5=1"; do
+for t in "" "2=1024" "2=768" "6=1" "0=128,1=64" "0=256,1=128"; do
   echo "== $t"
-  timeout -k 10 120 python bench.py --grid 150 --steps 2 --warmup 1 --no-cpu --tune "$t" | tail -1
+  timeout -k 10 120 python bench.py --grid 150 --steps 2 --warmup 1 --no-cpu --tune "$t" | python -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1])
+print(d['value'], d['ms_per_step'], d['config']['kernel_ms'], d['roofline']['achieved'], d['roofline']['launches'])"
 done
