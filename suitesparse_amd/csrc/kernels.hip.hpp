@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_potrf64(
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    bool failed = false;                                      // wave 0 only
+    int fail_col = 0;                                         // wave 0 only: 1-based column of the first bad pivot
 #pragma unroll 1
     for (int jb = 0; jb < 4; jb++) {
         const int c0 = 16 * jb;
@@ -516,11 +516,8 @@ __global__ __launch_bounds__(256) void k_potrf64(
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const double d = lane_bcast(a[j], j);
-                if (!(d > 0.0) && !failed) {
-                    failed = true;
-                    if (lane == 0 && info[t.s] == 0) info[t.s] = t.col0 + c0 + j + 1;
-                }
-                const double r = 1.0 / sqrt(d);
+                fail_col = (!(d > 0.0) && fail_col == 0) ? c0 + j + 1 : fail_col;
+                const double r = rsqrt(d);
                 rs[j] = r;
                 a[j] = (l15 == j) ? d * r : a[j] * r;
 #pragma unroll
@@ -576,6 +573,7 @@ __global__ __launch_bounds__(256) void k_potrf64(
         __syncthreads();
     }
 
+    if (tid == 0 && fail_col != 0 && info[t.s] == 0) info[t.s] = t.col0 + fail_col;
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int i = idx & (NB - 1), j = idx >> 6;
         if (i < nb && j < nb && i >= j) A[i + (int64_t)j * lda] = Ls[i][j];
