@@ -165,7 +165,8 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
 
 /* key 0: minimum M, key 1: minimum N of a task routed to the 128x128-tile kernel, key 2: outer
  * block width (affect factors created afterwards); key 3: retired; key 4: super-tile edge of the tile
- * order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks. */
+ * order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks; key 6: start
+ * stagger of k_gemm128 (experiment); key 7: second outer block width (0 = two blocking levels only). */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

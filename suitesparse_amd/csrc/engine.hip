@@ -687,7 +687,7 @@ int mi355_factor_set_profile(mi355_factor *F, int profile)
 
 // bare v_mfma_f64_16x16x4_f64 issue-rate probe: 4 independent accumulators per wave, operands in
 // registers, 4 waves per workgroup (one per SIMD), 2 workgroups per CU
-__global__ __launch_bounds__(256) void k_mfma_rate(int iters, double *out)
+__global__ __launch_bounds__(256, 2) void k_mfma_rate(int iters, double *out)
 {
     v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
@@ -716,6 +716,8 @@ int mi355_set_tuning(int key, int value)
     else if (key == 4) tuning().supertile = value;
     else if (key == 5) tuning().xcd_deal = value;
     else if (key == 6) tuning().stagger = value;
+    else if (key == 7) tuning().ob2 = value;
+    else if (key == 8) tuning().ob3 = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -1,5 +1,6 @@
 // schedule.cpp -- see schedule.hpp.  Pure host C++.
 #include "schedule.hpp"
+#include <cmath>
 #include <algorithm>
 #include <cstdio>
 
@@ -239,47 +240,55 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
         const int64_t ncol_eff = (truncated && s == s_limit) ? nscol2_limit : nscol;
 
         // ---- panel: blocked partial Cholesky of the nsrow x ncol_eff panel (a3.9 + a3.10)
+        // Right-looking with nested block widths W[0] = NB < W[1] < W[2] ...: when a width-W[i] block
+        // [b0, e) is complete, the columns [e, end of the enclosing W[i+1] block) receive its update in ONE
+        // GEMM of depth K = e - b0 (the outermost level updates to the end of the supernode).  Each C entry is
+        // read and written once per W[i] columns at level i, so the wide fronts do most of their flops at
+        // the largest K while the K = NB updates stay inside a W[1]-column window.
         size_t it = 0;
-        const int64_t ob = std::max(NB, (tuning().ob / NB) * NB);
-        for (int64_t J = 0; J < ncol_eff; J += ob) {
-            const int64_t Jend = std::min<int64_t>(J + ob, ncol_eff);
-            for (int64_t j = J; j < Jend; j += NB, it++) {
-                const int64_t nb = std::min<int64_t>(NB, Jend - j);
-                const int64_t below = nsrow - (j + nb);
-                L[lev].ensure(it);
-                PotrfTask pt;
-                pt.a_off = psx + j + j * nsrow;
-                pt.dinv_off = (below > 0) ? 0 : -1;     // slot assigned when the step is flushed
-                pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
-                pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
-                pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
-                L[lev].potrf[it].push_back(pt);
-                out.flops_panel += (double)nb * nb * nb / 3.0;
-                if (below > 0) {
-                    // X = B * inv(L11)^H  (trsm "R","L","C","N", worker :1175)
-                    GemmTask t = make_gemm(psx + (j + nb) + j * nsrow, /*b: slot, set later*/ 0,
-                                           psx + (j + nb) + j * nsrow, -1, nsrow, nb, nsrow,
-                                           below, nb, nb, GEMM_OVERWRITE);
-                    L[lev].trsm[it].push_back(t);
-                    out.flops_panel += (double)below * nb * nb;
-                    const int64_t ninner = Jend - (j + nb);
-                    if (ninner > 0) {
-                        L[lev].trail[it].push_back(make_gemm(
-                            psx + (j + nb) + j * nsrow, psx + (j + nb) + j * nsrow,
-                            psx + (j + nb) + (j + nb) * nsrow, -1, nsrow, nsrow, nsrow,
-                            below, ninner, nb, GEMM_DIRECT_SUB));
-                        out.flops_panel += ((double)ninner * ninner + 2.0 * (double)(below - ninner) * ninner) * nb;
-                    }
-                    if (j + nb == Jend && Jend < ncol_eff) {
-                        const int64_t K = Jend - J;
-                        L[lev].trail[it].push_back(make_gemm(
-                            psx + Jend + J * nsrow, psx + Jend + J * nsrow,
-                            psx + Jend + Jend * nsrow, -1, nsrow, nsrow, nsrow,
-                            nsrow - Jend, ncol_eff - Jend, K, GEMM_DIRECT_SUB));
-                        { const double Nn = (double)(ncol_eff - Jend), Mm = (double)(nsrow - Jend);
-                          out.flops_panel += (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * K; }
-                    }
-                }
+        std::vector<int64_t> W;
+        W.push_back(NB);
+        {
+            const int64_t w1 = std::max(NB, (tuning().ob / NB) * NB);
+            if (w1 > W.back()) W.push_back(w1);
+            const int64_t w2 = (tuning().ob2 / NB) * NB;
+            if (w2 > W.back() && w2 % W.back() == 0) W.push_back(w2);
+            const int64_t w3 = (tuning().ob3 / NB) * NB;
+            if (w3 > W.back() && w3 % W.back() == 0) W.push_back(w3);
+        }
+        for (int64_t j = 0; j < ncol_eff; j += NB, it++) {
+            const int64_t nb = std::min<int64_t>(NB, ncol_eff - j);
+            const int64_t e = j + nb;
+            const int64_t below = nsrow - e;
+            L[lev].ensure(it);
+            PotrfTask pt;
+            pt.a_off = psx + j + j * nsrow;
+            pt.dinv_off = (below > 0) ? 0 : -1;     // slot assigned when the step is flushed
+            pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
+            pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
+            pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
+            L[lev].potrf[it].push_back(pt);
+            out.flops_panel += (double)nb * nb * nb / 3.0;
+            if (below <= 0) continue;
+            // X = B * inv(L11)^H  (trsm "R","L","C","N", worker :1175)
+            GemmTask t = make_gemm(psx + e + j * nsrow, /*b: slot, set later*/ 0,
+                                   psx + e + j * nsrow, -1, nsrow, nb, nsrow,
+                                   below, nb, nb, GEMM_OVERWRITE);
+            L[lev].trsm[it].push_back(t);
+            out.flops_panel += (double)below * nb * nb;
+            for (size_t lvl = 0; lvl < W.size(); lvl++) {
+                const int64_t b0 = ((e - 1) / W[lvl]) * W[lvl];                       // block of this level ending at e?
+                if (std::min<int64_t>(b0 + W[lvl], ncol_eff) != e) break;
+                const int64_t enc_end = (lvl + 1 < W.size())
+                    ? std::min<int64_t>((b0 / W[lvl + 1]) * W[lvl + 1] + W[lvl + 1], ncol_eff) : ncol_eff;
+                if (enc_end <= e) continue;                                           // enclosing block complete too
+                const int64_t K = e - b0, Nn = enc_end - e;
+                L[lev].trail[it].push_back(make_gemm(
+                    psx + e + b0 * nsrow, psx + e + b0 * nsrow,
+                    psx + e + e * nsrow, -1, nsrow, nsrow, nsrow,
+                    below, Nn, K, GEMM_DIRECT_SUB));
+                out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
+                break;
             }
         }
 

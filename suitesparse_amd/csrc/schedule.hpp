@@ -22,7 +22,7 @@
 namespace mi355 {
 
 constexpr int NB = 64;        // diagonal-block / panel width of the device POTRF
-constexpr int OB = 512;       // outer block (trailing updates with K = OB); 512 measured best at 150^3
+constexpr int OB = 256;       // default first outer block width (Tuning::ob); nested widths 64 / 256 / 1024 measured best at 150^3
 constexpr int TILE = 64;      // GEMM output tile (TILE x TILE per workgroup), small-tile kernel
 constexpr int BTILE = 128;    // big-tile kernel
 constexpr int SOLVE_ROWS = 64;   // rows of L per workgroup (tile) in the solve update kernels
@@ -132,7 +132,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     const int8_t *mask = nullptr);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = OB; int supertile = 8; int xcd_deal = 0; int stagger = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int stagger = 0; int ob2 = 1024; int ob3 = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -106,6 +106,18 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
 
 extern "C" {
 
+// schedule tuning of the emulator's own copy of schedule.cpp (2: outer block width, 7: second outer block width)
+void emu_set_tuning(int key, int value)
+{
+    if (key == 0) tuning().big_min_m = value;
+    else if (key == 1) tuning().big_min_n = value;
+    else if (key == 2) tuning().ob = value;
+    else if (key == 4) tuning().supertile = value;
+    else if (key == 5) tuning().xcd_deal = value;
+    else if (key == 7) tuning().ob2 = value;
+    else if (key == 8) tuning().ob3 = value;
+}
+
 // returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them
 int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
                       const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,

@@ -65,10 +65,11 @@ def test_quick_return_if_not_posdef(engine, name):
     assert np.array_equal(Lx == 0, Lo == 0)
 
 
-@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 256, 257, 300, 700])
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 256, 257, 300, 700, 1100, 1733])
 def test_dense_single_supernode(engine, n):
     """one dense supernode: exercises POTRF blocks, TRSM-by-inverse, inner (K=64) and outer
-    (K=256) trailing updates with ragged edges."""
+    (K=512) trailing updates with ragged edges; from 1025 columns on also the column slices of the outer
+    update that ride with the next block's inner launches."""
     rng = np.random.default_rng(n)
     M = rng.standard_normal((n, n))
     A = M @ M.T + n * np.eye(n)

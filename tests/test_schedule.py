@@ -54,6 +54,31 @@ def backward_error_S(g, X):
 REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
 
 
+@pytest.mark.parametrize("n,ob,ob2", [(700, 128, 0), (700, 128, 256), (1000, 192, 576), (333, 64, 128), (1300, 512, 1024),
+                                      (900, 128, 512), (130, 512, 2048)])
+def test_dense_supernode_blocking(emu, n, ob, ob2):
+    """one dense supernode through the emulator with small nested block widths (64 < ob < ob2): every entry
+    must be updated exactly once by every earlier column (compared with numpy's Cholesky)."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    g = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n], dtype=np.int64),
+             Lpi=np.array([0, n], dtype=np.int64), Lpx=np.array([0, n * n], dtype=np.int64),
+             Ls=np.arange(n, dtype=np.int64), Sp=np.arange(n + 1, dtype=np.int64) * n,
+             Si=np.tile(np.arange(n, dtype=np.int64), n), Sx=np.ascontiguousarray(A.T).reshape(-1), beta=0.0)
+    emu.emu_set_tuning(2, ob)
+    emu.emu_set_tuning(7, ob2)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(2, 256)
+        emu.emu_set_tuning(7, 1024)
+    assert st == 0 and minor == n
+    Lg = Lx.reshape(n, n).T
+    assert np.all(np.triu(Lg, 1) == 0)
+    assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
+
+
 @pytest.mark.parametrize("name", REAL)
 def test_schedule_reproduces_reference(emu, name):
     g = load_golden(name)

@@ -13,7 +13,7 @@ for line in open(sys.argv[1]):
     else:
         k = int(d["kmax"])
         kb = "K<=64" if k <= 64 else "K<=128" if k <= 128 else "K<=256" if k <= 256 else "K<=512" if k <= 512 else "K>512"
-        key = ("gemm128" if d["big"] == "1" else "gemm64", {"0": "overwrite(trsm)", "1": "direct_sub(trail)", "2": "scatter(update)"}[d["mode"]], kb)
+        key = ("gemm128" if d["big"] == "1" else "gemm64", {"0": "scatter(update)", "1": "direct_sub(trail)", "2": "overwrite(trsm)"}[d["mode"]], kb)
         fl, nt = float(d["flops"]), int(d["ntiles"])
     e = g[key]; e[0] += 1; e[1] += ms; e[2] += fl; e[3] += nt
 print(f"{'kernel':8s} {'mode':18s} {'K':7s} {'launches':>8s} {'ms':>9s} {'%':>6s} {'TFLOP':>8s} {'TF/s':>7s} {'tiles/launch':>12s}")
