@@ -272,3 +272,70 @@ def test_complex_hermitian_vs_live_reference(engine, size, nrhs, have_ref):
     X = np.empty_like(Xg)
     X[sym["Perm"]] = Xg
     assert problems.backward_error(p, X, B) <= 10 * problems.backward_error(p, r.solve(B), B) + 1e-18
+
+
+def _grid_problem(grid):
+    from suitesparse_amd import problems, symbolic
+    p = problems.laplacian_3d(grid)
+    perm = symbolic.nd_grid_order((grid, grid, grid), 1)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], perm)
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    return p, sym, Sp, Si, Sx
+
+
+@pytest.mark.parametrize("grid", [60, 150])
+def test_full_size_properties(engine, grid):
+    """BASELINE-size runs (150^3 = config 3, the bench workload) checked through size-independent properties:
+    b = S*1 solves back to 1 with a backward error at rounding level, the solve is linear, and a second
+    factorization of the same matrix reproduces the first one to the atomics' summation-order noise."""
+    import scipy.sparse as sp
+    import torch
+    p, sym, Sp, Si, Sx = _grid_problem(grid)
+    n = p["n"]
+    S = sp.csc_matrix((Sx, Si, Sp), shape=(n, n))
+    A = (S + S.T - sp.diags(S.diagonal())).tocsr()
+    L = engine.SupernodalFactor(sym)
+    L.set_matrix(Sp, Si, Sx)
+    assert L.numeric() == 0 and L.minor == n
+    ones = np.ones(n)
+    b = A @ ones
+    rng = np.random.default_rng(grid)
+    c = rng.standard_normal(n)
+    B = np.stack([b, c, 2.0 * b - 3.0 * c], axis=1)            # n x 3, third column = combination of the others
+    X = torch.from_numpy(np.asfortranarray(B).T.copy()).cuda()  # column-major n x 3 on the device
+    L.solve_dev(X.data_ptr(), 3, n, lower=True)
+    L.solve_dev(X.data_ptr(), 3, n, lower=False)
+    Xh = X.cpu().numpy().T                                       # n x 3
+    anorm = abs(A).sum(axis=1).max()
+    for j in range(3):
+        r = A @ Xh[:, j] - B[:, j]
+        assert np.abs(r).max() / (anorm * np.abs(Xh[:, j]).max() + np.abs(B[:, j]).max()) < 1e-14
+    assert np.abs(Xh[:, 0] - 1.0).max() < 1e-9
+    assert np.abs(Xh[:, 2] - (2.0 * Xh[:, 0] - 3.0 * Xh[:, 1])).max() < 1e-9 * np.abs(Xh).max()
+    # refactorization: same structure, values equal up to summation order
+    Y0 = X.clone()
+    assert L.numeric() == 0
+    X2 = torch.from_numpy(np.asfortranarray(B).T.copy()).cuda()
+    L.solve_dev(X2.data_ptr(), 3, n, lower=True)
+    L.solve_dev(X2.data_ptr(), 3, n, lower=False)
+    assert float((X2 - Y0).abs().max()) < 1e-9 * float(Y0.abs().max())
+
+
+def test_not_posdef_minor_at_scale(engine):
+    """one negated diagonal entry at a known permuted column k of a 60^3 Laplacian: the pivot of column k is
+    the first that fails, so L->minor = k exactly and the columns from k on are zero (worker :1084-1146)."""
+    p, sym, Sp, Si, Sx = _grid_problem(60)
+    n = p["n"]
+    k = int(sym["Super"][sym["nsuper"] * 2 // 3]) + 1
+    Sx = Sx.copy()
+    assert Si[Sp[k]] == k
+    Sx[Sp[k]] = -Sx[Sp[k]]
+    L = engine.SupernodalFactor(sym)
+    st = L.super_numeric(Sp, Si, Sx)
+    assert st == 1 and L.minor == k
+    Lx = L.Lx()
+    s = int(np.searchsorted(sym["Super"], k, side="right") - 1)
+    nsrow = int(sym["Lpi"][s + 1] - sym["Lpi"][s])
+    start = int(sym["Lpx"][s]) + nsrow * (k - int(sym["Super"][s]))
+    assert not Lx[start:].any()                                  # column k of s and everything after it
+    assert Lx[:start].any()
