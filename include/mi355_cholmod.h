@@ -129,6 +129,34 @@ int mi355_super_ltsolve(mi355_factor *handle, int64_t nrhs, double *X, int64_t d
 int mi355_super_lsolve_dev(mi355_factor *handle, int64_t nrhs, double *X_dev, int64_t d);
 int mi355_super_ltsolve_dev(mi355_factor *handle, int64_t nrhs, double *X_dev, int64_t d);
 
+/* ---- solve with the permutation on the device: replaces the supernodal branch of cholmod_solve2
+ *      (CHOLMOD/Cholesky/cholmod_solve.c:656-717: Y = P*B, super_lsolve, super_ltsolve, X = P'*Y) and its
+ *      P / Pt systems (:622-655).  sys takes CHOLMOD's values (cholmod.h, CHOLMOD_A ... CHOLMOD_Pt); for an
+ *      LL' factor D is the identity; exactly as the reference, A and LDLt run both
+ *      sweeps, L/LD the forward one, Lt/DLt the backward one, D copies; Perm is applied for A, P and Pt only
+ *      (cholmod_solve.c:262-270).  B and X are n x nrhs, column-major, E doubles per entry. */
+#define MI355_SYS_A    0
+#define MI355_SYS_LDLt 1
+#define MI355_SYS_LD   2
+#define MI355_SYS_DLt  3
+#define MI355_SYS_L    4
+#define MI355_SYS_Lt   5
+#define MI355_SYS_D    6
+#define MI355_SYS_P    7
+#define MI355_SYS_Pt   8
+
+/* L->Perm (n entries, copied to the device; NULL = natural ordering).  Checked to be a permutation. */
+int mi355_factor_set_perm(mi355_factor *handle, const int64_t *Perm);
+
+/* host B (ld ldb) -> host X (ld ldx) */
+int mi355_solve(mi355_factor *handle, int sys, int64_t nrhs, const double *B, int64_t ldb,
+                double *X, int64_t ldx);
+
+/* device B -> device X; everything (both permutations, both sweeps) stays in HBM.  X may alias B except
+ * for the P and Pt systems. */
+int mi355_solve_dev(mi355_factor *handle, int sys, int64_t nrhs, const double *B_dev, int64_t ldb,
+                    double *X_dev, int64_t ldx);
+
 /* ---- instrumentation: replaces the -DBLAS_TIMER counters
  *      (worker :246-266,:763-811; Common->cholmod_gpu_*_time, cholmod.h:966-986) */
 

@@ -87,6 +87,9 @@ struct mi355_factor_s {
     Symbolic sym;
     // device
     DevBuf<double> Lx, Dinv;
+    DevBuf<int64_t> dPerm;                 // L->Perm for mi355_solve (empty: identity)
+    DevBuf<double> Ywork;                  // n x nrhs workspace of mi355_solve (grown on demand)
+    size_t ywork_cap = 0;
     DevBuf<int32_t> dLs, dSupermap;
     DevBuf<int64_t> dSuper, dLpi, dLpx;
     DevBuf<int> info;           // nsuper + 2 (first-failure scratch at [nsuper], [nsuper+1])
@@ -674,6 +677,106 @@ int mi355_super_ltsolve_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
     int rc = check_handle(F);
     if (rc) return rc;
     return solve_dev(F, false, nrhs, X, d);
+}
+
+// Y(k,:) = B(Perm[k],:)  (gather = true;  d_perm, CHOLMOD/Cholesky/cholmod_solve.c:689)   or
+// X(Perm[k],:) = Y(k,:)  (gather = false; d_iperm, :712); E doubles per entry; perm == nullptr: identity
+__global__ __launch_bounds__(256) void k_permute_rows(int64_t n, int nrhs, int E, const int64_t *__restrict__ perm,
+                                                      const double *__restrict__ src, int64_t lds_, double *__restrict__ dst,
+                                                      int64_t ldd, int gather)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t pk = perm ? perm[k] : k;
+    const int64_t rs = gather ? pk : k, rd = gather ? k : pk;
+    for (int j = 0; j < nrhs; j++)
+        for (int e = 0; e < E; e++) dst[(rd + (int64_t)j * ldd) * E + e] = src[(rs + (int64_t)j * lds_) * E + e];
+}
+
+int mi355_factor_set_perm(mi355_factor *F, const int64_t *Perm)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    F->dPerm.release();
+    if (!Perm) return MI355_OK;
+    const int64_t n = F->sym.n;
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t p = Perm[k];
+        if (p < 0 || p >= n || seen[(size_t)p]) return fail(MI355_INVALID, "Perm is not a permutation of 0..n-1");
+        seen[(size_t)p] = 1;
+    }
+    HIP_TRY(F->dPerm.upload(Perm, (size_t)n, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
+}
+
+int mi355_solve_dev(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const int64_t n = F->sym.n;
+    if (sys < MI355_SYS_A || sys > MI355_SYS_Pt) return fail(MI355_INVALID, "invalid system");
+    if (nrhs < 0 || ldb < n || ldx < n) return fail(MI355_INVALID, "dimensions of L, X and B do not match");
+    if (n == 0 || nrhs == 0) return MI355_OK;
+    if (!B || !X) return fail(MI355_INVALID, "null argument");
+    if (nrhs > 0x7fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
+    const int E = F->E, nr = (int)nrhs;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    // Perm is used for A, P and Pt only (cholmod_solve.c:262-270); the other systems run unpermuted
+    const bool use_perm = (sys == MI355_SYS_A || sys == MI355_SYS_P || sys == MI355_SYS_Pt);
+    const int64_t *perm = use_perm ? F->dPerm.p : nullptr;
+    if (sys == MI355_SYS_P || sys == MI355_SYS_Pt) {
+        if (B == X) return fail(MI355_INVALID, "P and Pt systems need X != B");
+        hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, B, ldb, X, ldx,
+                           sys == MI355_SYS_P ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(F->stream));
+        return MI355_OK;
+    }
+    const size_t need = (size_t)n * (size_t)nrhs * (size_t)E;
+    if (need > F->ywork_cap) {
+        F->Ywork.release();
+        F->ywork_cap = 0;
+        HIP_TRY(F->Ywork.alloc(need));
+        F->ywork_cap = need;
+    }
+    double *Y = F->Ywork.p;
+    hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, B, ldb, Y, n, 1);   // Y = P*B
+    HIP_TRY(hipGetLastError());
+    double ms = 0;
+    const bool fwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_L || sys == MI355_SYS_LD);
+    const bool bwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_Lt || sys == MI355_SYS_DLt);
+    if (fwd) { rc = solve_dev(F, true, nrhs, Y, n); if (rc) return rc; ms += F->st_solve; }
+    if (bwd) { rc = solve_dev(F, false, nrhs, Y, n); if (rc) return rc; ms += F->st_solve; }
+    F->st_solve = ms;
+    hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, Y, n, X, ldx, 0);   // X = P'*Y
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
+}
+
+int mi355_solve(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const int64_t n = F->sym.n;
+    if (nrhs < 0 || ldb < n || ldx < n) return fail(MI355_INVALID, "dimensions of L, X and B do not match");
+    if (n == 0 || nrhs == 0) return MI355_OK;
+    if (!B || !X) return fail(MI355_INVALID, "null argument");
+    const size_t es = (size_t)F->E * sizeof(double);
+    DevBuf<double> dB, dX;
+    HIP_TRY(dB.alloc((size_t)n * nrhs * F->E));
+    HIP_TRY(dX.alloc((size_t)n * nrhs * F->E));
+    HIP_TRY(hipMemcpy2DAsync(dB.p, n * es, B, ldb * es, n * es, (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
+    rc = mi355_solve_dev(F, sys, nrhs, dB.p, n, dX.p, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(X, ldx * es, dX.p, n * es, n * es, (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
 }
 
 double *mi355_factor_device_Lx(mi355_factor *F) { return F ? F->Lx.p : nullptr; }

@@ -35,6 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
+    "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev",
 ]
 
 _LIB = None
@@ -70,6 +71,9 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int64]
         for f in (L.mi355_super_lsolve_dev, L.mi355_super_ltsolve_dev):
             f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_factor_set_perm.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, _f64p, C.c_int64, _f64p, C.c_int64]
+        L.mi355_solve_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.mi355_factor_device_Lx.argtypes = [C.c_void_p]
         L.mi355_factor_device_Lx.restype = C.c_void_p
         L.mi355_factor_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -231,6 +235,37 @@ class SupernodalFactor:
     def super_ltsolve(self, X):
         """x = L' \\ b (cholmod_super_ltsolve)."""
         return self._solve(lib().mi355_super_ltsolve, X)
+
+    def set_perm(self, Perm):
+        """L->Perm for solve() (None: natural ordering)."""
+        if Perm is None:
+            _check(lib().mi355_factor_set_perm(self._h, None))
+        else:
+            P = np.ascontiguousarray(Perm, dtype=np.int64)
+            _check(lib().mi355_factor_set_perm(self._h, P.ctypes.data_as(C.c_void_p)))
+
+    def solve(self, B, sys=0):
+        """cholmod_solve(sys, L, B) for the supernodal factor: sys = CHOLMOD_A (0) ... CHOLMOD_Pt (8);
+        permutations and sweeps run on the device (cholmod_solve.c:656-717)."""
+        dt = np.complex128 if self.E == 2 else np.float64
+        if self.E == 1 and np.iscomplexobj(B):
+            raise Mi355Error(CHOLMOD_INVALID, "L and B must have the same xtype")
+        B = np.asarray(B, dtype=dt)
+        one_d = B.ndim == 1
+        if one_d:
+            B = B[:, None]
+        n, nrhs = B.shape
+        bb = np.array(B.T, dtype=dt, order="C", copy=True)
+        xx = np.zeros_like(bb)
+        if bb.size:
+            _check(lib().mi355_solve(self._h, int(sys), nrhs, bb.view(np.float64).reshape(-1), n,
+                                     xx.view(np.float64).reshape(-1), n))
+        out = xx.T.copy()
+        return out[:, 0] if one_d else out
+
+    def solve2_dev(self, sys, B_ptr, ldb, X_ptr, ldx, nrhs):
+        _check(lib().mi355_solve_dev(self._h, int(sys), int(nrhs), C.c_void_p(int(B_ptr)), int(ldb),
+                                     C.c_void_p(int(X_ptr)), int(ldx)))
 
     def solve_dev(self, X_ptr, nrhs, d, lower=True):
         fn = lib().mi355_super_lsolve_dev if lower else lib().mi355_super_ltsolve_dev

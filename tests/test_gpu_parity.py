@@ -339,3 +339,72 @@ def test_not_posdef_minor_at_scale(engine):
     start = int(sym["Lpx"][s]) + nsrow * (k - int(sym["Super"][s]))
     assert not Lx[start:].any()                                  # column k of s and everything after it
     assert Lx[:start].any()
+
+
+@pytest.mark.parametrize("kind,size,nrhs", [("lap3d", 16, 1), ("lap2d", 60, 4), ("elast", 6, 2)])
+def test_solve_with_permutation_vs_reference(engine, kind, size, nrhs, have_ref):
+    """mi355_solve (Y = P*B, both sweeps, X = P'*Y on the device) against the reference's cholmod_l_solve
+    (CHOLMOD/Cholesky/cholmod_solve.c:656-717), plus every other `sys` against its definition."""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d,
+         "elast": problems.elasticity27}[kind](size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    perm = np.asarray(sym["Perm"], dtype=np.int64)
+    L = engine.SupernodalFactor(sym)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    L.set_perm(perm)
+    B = problems.demo_rhs(p["n"], nrhs)
+    if B.ndim == 1:
+        B = B[:, None]
+    Xr = r.solve(B)
+    Xg = L.solve(B, 0)                                   # CHOLMOD_A
+    assert relerr(Xg, Xr) < 1e-9
+    assert problems.backward_error(p, Xg, B) <= 10 * problems.backward_error(p, Xr, B) + 1e-18
+    # the other systems, from their definitions (cholmod_solve.c:14-24)
+    Yl = L.super_lsolve(B)
+    assert relerr(L.solve(B, 4), Yl) < 1e-12             # L   (no permutation)
+    assert relerr(L.solve(B, 2), Yl) < 1e-12             # LD  (D = I for LL')
+    Yt = L.super_ltsolve(B)
+    assert relerr(L.solve(B, 5), Yt) < 1e-12             # Lt
+    assert relerr(L.solve(B, 3), Yt) < 1e-12             # DLt
+    assert relerr(L.solve(B, 1), L.super_ltsolve(Yl)) < 1e-12   # LDLt = both sweeps, no permutation
+    assert np.array_equal(L.solve(B, 6), B)              # D
+    assert np.array_equal(L.solve(B, 7), B[perm])        # P:  x = P b
+    Z = np.empty_like(B)
+    Z[perm] = B
+    assert np.array_equal(L.solve(B, 8), Z)              # Pt: x = P' b
+    # natural ordering after set_perm(None)
+    L.set_perm(None)
+    assert relerr(L.solve(B, 0), L.super_ltsolve(Yl)) < 1e-12
+    with pytest.raises(engine.Mi355Error):
+        L.solve(B, 9)
+    with pytest.raises(engine.Mi355Error):
+        L.set_perm(np.zeros(p["n"], dtype=np.int64))
+
+
+def test_solve_complex_with_permutation(engine, have_ref):
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = problems.helmholtz_3d(10)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    L = engine.SupernodalFactor(sym, xtype=2)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    L.set_perm(sym["Perm"])
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((p["n"], 3)) + 1j * rng.standard_normal((p["n"], 3))
+    assert relerr(L.solve(B, 0), r.solve(B)) < 1e-9
