@@ -157,6 +157,15 @@ int mi355_solve(mi355_factor *handle, int sys, int64_t nrhs, const double *B, in
 int mi355_solve_dev(mi355_factor *handle, int sys, int64_t nrhs, const double *B_dev, int64_t ldb,
                     double *X_dev, int64_t ldx);
 
+/* The same with a right-hand side whose xtype differs from L's (cholmod_solve.c:228-235,668;
+ * t_cholmod_psolve_worker.c:83-240): bxtype = MI355_REAL or MI355_COMPLEX (interleaved).  X is complex if
+ * either L or B is.  A complex B under a real L is solved as 2*nrhs real right-hand sides ("dual"); a real
+ * B under a complex L gets a zero imaginary part.  (Zomplex B/X: interleave on the host first.) */
+int mi355_solve_x(mi355_factor *handle, int sys, int64_t nrhs, int bxtype, const double *B, int64_t ldb,
+                  double *X, int64_t ldx);
+int mi355_solve_x_dev(mi355_factor *handle, int sys, int64_t nrhs, int bxtype, const double *B_dev,
+                      int64_t ldb, double *X_dev, int64_t ldx);
+
 /* ---- instrumentation: replaces the -DBLAS_TIMER counters
  *      (worker :246-266,:763-811; Common->cholmod_gpu_*_time, cholmod.h:966-986) */
 

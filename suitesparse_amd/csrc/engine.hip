@@ -620,10 +620,29 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         for (size_t i = steps.size(); i-- > 0;) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
-            if (st.stiles > 0)
-                hipLaunchKernelGGL(cplx ? k_solve_bwd_update_c : k_solve_bwd_update, dim3((unsigned)st.stiles),
-                                   dim3(256), 0, F->stream,
-                                   P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+            if (st.stiles > 0) {
+                if (cplx) {
+                    hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
+                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+                } else if (nr <= SOLVE_NR) {
+                    // a workgroup walks `group` table entries: fewer atomics into the same 64 x nrhs entries of a
+                    // tall block, while at least ~128 workgroups stay per launch
+                    const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 128));
+                    const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
+                    if (nr == 1)
+                        hipLaunchKernelGGL(k_solve_bwd_update<1>, dim3(grid), dim3(256), 0, F->stream,
+                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nr);
+                    else
+                        hipLaunchKernelGGL(k_solve_bwd_update<SOLVE_NR>, dim3(grid), dim3(256), 0, F->stream,
+                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nr);
+                } else {
+                    hipLaunchKernelGGL(k_solve_bwd_update<0>, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
+                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, 1,
+                                       F->Lx.p, F->dLs.p, X, d, nr);
+                }
+            }
             hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
                                0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             HIP_TRY(hipGetLastError());
@@ -679,18 +698,46 @@ int mi355_super_ltsolve_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
     return solve_dev(F, false, nrhs, X, d);
 }
 
-// Y(k,:) = B(Perm[k],:)  (gather = true;  d_perm, CHOLMOD/Cholesky/cholmod_solve.c:689)   or
-// X(Perm[k],:) = Y(k,:)  (gather = false; d_iperm, :712); E doubles per entry; perm == nullptr: identity
-__global__ __launch_bounds__(256) void k_permute_rows(int64_t n, int nrhs, int E, const int64_t *__restrict__ perm,
-                                                      const double *__restrict__ src, int64_t lds_, double *__restrict__ dst,
-                                                      int64_t ldd, int gather)
+// Y(k,:) = B(Perm[k],:)  (gather: d_perm, CHOLMOD/Cholesky/cholmod_solve.c:689,
+// t_cholmod_psolve_worker.c:40-240)   or   X(Perm[k],:) = Y(k,:)  (scatter: d_iperm, :712, worker :251-420).
+// The permuted side P (B or X) has Ep doubles per entry and leading dimension ldp; the workspace side Y has Ey
+// doubles per entry, ld ldy, or -- dual: a real L with a complex right-hand side -- two real columns per
+// right-hand side (real part in column 2j, imaginary part in column 2j+1, worker :102-115).  A real B under a
+// complex L gets a zero imaginary part.  perm == nullptr: identity.
+__global__ __launch_bounds__(256) void k_permute_rows(int64_t n, int nrhs, const int64_t *__restrict__ perm,
+                                                      const double *__restrict__ src, double *__restrict__ dst,
+                                                      int64_t ldp, int Ep, int64_t ldy, int Ey, int dual, int gather)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t pk = perm ? perm[k] : k;
-    const int64_t rs = gather ? pk : k, rd = gather ? k : pk;
-    for (int j = 0; j < nrhs; j++)
-        for (int e = 0; e < E; e++) dst[(rd + (int64_t)j * ldd) * E + e] = src[(rs + (int64_t)j * lds_) * E + e];
+    for (int j = 0; j < nrhs; j++) {
+        if (gather) {
+            const double *b = src + (pk + (int64_t)j * ldp) * Ep;
+            const double re = b[0], im = (Ep == 2) ? b[1] : 0.0;
+            if (dual) {
+                dst[k + (int64_t)(2 * j) * ldy] = re;
+                dst[k + (int64_t)(2 * j + 1) * ldy] = im;
+            } else {
+                double *y = dst + (k + (int64_t)j * ldy) * Ey;
+                y[0] = re;
+                if (Ey == 2) y[1] = im;
+            }
+        } else {
+            double re, im;
+            if (dual) {
+                re = src[k + (int64_t)(2 * j) * ldy];
+                im = src[k + (int64_t)(2 * j + 1) * ldy];
+            } else {
+                const double *y = src + (k + (int64_t)j * ldy) * Ey;
+                re = y[0];
+                im = (Ey == 2) ? y[1] : 0.0;
+            }
+            double *x = dst + (pk + (int64_t)j * ldp) * Ep;
+            x[0] = re;
+            if (Ep == 2) x[1] = im;
+        }
+    }
 }
 
 int mi355_factor_set_perm(mi355_factor *F, const int64_t *Perm)
@@ -712,31 +759,31 @@ int mi355_factor_set_perm(mi355_factor *F, const int64_t *Perm)
     return MI355_OK;
 }
 
-int mi355_solve_dev(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+int mi355_solve_x_dev(mi355_factor *F, int sys, int64_t nrhs, int bxtype, const double *B, int64_t ldb,
+                      double *X, int64_t ldx)
 {
     g_err.clear();
     int rc = check_handle(F);
     if (rc) return rc;
     const int64_t n = F->sym.n;
     if (sys < MI355_SYS_A || sys > MI355_SYS_Pt) return fail(MI355_INVALID, "invalid system");
+    if (bxtype != MI355_REAL && bxtype != MI355_COMPLEX) return fail(MI355_INVALID, "B must be real or complex (interleaved)");
     if (nrhs < 0 || ldb < n || ldx < n) return fail(MI355_INVALID, "dimensions of L, X and B do not match");
     if (n == 0 || nrhs == 0) return MI355_OK;
     if (!B || !X) return fail(MI355_INVALID, "null argument");
-    if (nrhs > 0x7fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
+    if (nrhs > 0x3fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
     const int E = F->E, nr = (int)nrhs;
+    const int Eb = (bxtype == MI355_COMPLEX) ? 2 : 1;
+    const int Ex = (Eb == 2 || E == 2) ? 2 : 1;                 // xtype of X (cholmod_solve.c:228-235)
+    const int dual = (E == 1 && Eb == 2) ? 1 : 0;               // real L, complex B (cholmod_solve.c:668)
     const unsigned grid = (unsigned)((n + 255) / 256);
     // Perm is used for A, P and Pt only (cholmod_solve.c:262-270); the other systems run unpermuted
     const bool use_perm = (sys == MI355_SYS_A || sys == MI355_SYS_P || sys == MI355_SYS_Pt);
     const int64_t *perm = use_perm ? F->dPerm.p : nullptr;
-    if (sys == MI355_SYS_P || sys == MI355_SYS_Pt) {
-        if (B == X) return fail(MI355_INVALID, "P and Pt systems need X != B");
-        hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, B, ldb, X, ldx,
-                           sys == MI355_SYS_P ? 1 : 0);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(F->stream));
-        return MI355_OK;
-    }
-    const size_t need = (size_t)n * (size_t)nrhs * (size_t)E;
+    if (B == X && (sys == MI355_SYS_P || sys == MI355_SYS_Pt || Ex != Eb))
+        return fail(MI355_INVALID, "X must not alias B for this system");
+    const int64_t nry = dual ? 2 * nrhs : nrhs;                 // columns of Y
+    const size_t need = (size_t)n * (size_t)nry * (size_t)E;
     if (need > F->ywork_cap) {
         F->Ywork.release();
         F->ywork_cap = 0;
@@ -744,39 +791,63 @@ int mi355_solve_dev(mi355_factor *F, int sys, int64_t nrhs, const double *B, int
         F->ywork_cap = need;
     }
     double *Y = F->Ywork.p;
-    hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, B, ldb, Y, n, 1);   // Y = P*B
+    if (sys == MI355_SYS_Pt) {
+        // x = P'*b: no gather; b goes through Y unpermuted, then the scatter
+        hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, (const int64_t *)nullptr,
+                           B, Y, ldb, Eb, n, E, dual, 1);
+    } else {
+        hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, perm,
+                           B, Y, ldb, Eb, n, E, dual, 1);                                   // Y = P*B
+    }
     HIP_TRY(hipGetLastError());
     double ms = 0;
     const bool fwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_L || sys == MI355_SYS_LD);
     const bool bwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_Lt || sys == MI355_SYS_DLt);
-    if (fwd) { rc = solve_dev(F, true, nrhs, Y, n); if (rc) return rc; ms += F->st_solve; }
-    if (bwd) { rc = solve_dev(F, false, nrhs, Y, n); if (rc) return rc; ms += F->st_solve; }
+    if (fwd) { rc = solve_dev(F, true, nry, Y, n); if (rc) return rc; ms += F->st_solve; }
+    if (bwd) { rc = solve_dev(F, false, nry, Y, n); if (rc) return rc; ms += F->st_solve; }
     F->st_solve = ms;
-    hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, E, perm, Y, n, X, ldx, 0);   // X = P'*Y
+    const int64_t *sperm = (sys == MI355_SYS_A || sys == MI355_SYS_Pt) ? perm : nullptr;     // X = P'*Y, or X = Y
+    hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, sperm,
+                       (const double *)Y, X, ldx, Ex, n, E, dual, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(F->stream));
     return MI355_OK;
 }
 
-int mi355_solve(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+int mi355_solve_x(mi355_factor *F, int sys, int64_t nrhs, int bxtype, const double *B, int64_t ldb,
+                  double *X, int64_t ldx)
 {
     g_err.clear();
     int rc = check_handle(F);
     if (rc) return rc;
     const int64_t n = F->sym.n;
+    if (bxtype != MI355_REAL && bxtype != MI355_COMPLEX) return fail(MI355_INVALID, "B must be real or complex (interleaved)");
     if (nrhs < 0 || ldb < n || ldx < n) return fail(MI355_INVALID, "dimensions of L, X and B do not match");
     if (n == 0 || nrhs == 0) return MI355_OK;
     if (!B || !X) return fail(MI355_INVALID, "null argument");
-    const size_t es = (size_t)F->E * sizeof(double);
+    const int Eb = (bxtype == MI355_COMPLEX) ? 2 : 1, Ex = (Eb == 2 || F->E == 2) ? 2 : 1;
+    const size_t bs = (size_t)Eb * sizeof(double), xs = (size_t)Ex * sizeof(double);
     DevBuf<double> dB, dX;
-    HIP_TRY(dB.alloc((size_t)n * nrhs * F->E));
-    HIP_TRY(dX.alloc((size_t)n * nrhs * F->E));
-    HIP_TRY(hipMemcpy2DAsync(dB.p, n * es, B, ldb * es, n * es, (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
-    rc = mi355_solve_dev(F, sys, nrhs, dB.p, n, dX.p, n);
+    HIP_TRY(dB.alloc((size_t)n * nrhs * Eb));
+    HIP_TRY(dX.alloc((size_t)n * nrhs * Ex));
+    HIP_TRY(hipMemcpy2DAsync(dB.p, n * bs, B, ldb * bs, n * bs, (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
+    rc = mi355_solve_x_dev(F, sys, nrhs, bxtype, dB.p, n, dX.p, n);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(X, ldx * es, dX.p, n * es, n * es, (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipMemcpy2DAsync(X, ldx * xs, dX.p, n * xs, n * xs, (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
     HIP_TRY(hipStreamSynchronize(F->stream));
     return MI355_OK;
+}
+
+int mi355_solve_dev(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+{
+    if (!F) return fail(MI355_INVALID, "null factor handle");
+    return mi355_solve_x_dev(F, sys, nrhs, F->E == 2 ? MI355_COMPLEX : MI355_REAL, B, ldb, X, ldx);
+}
+
+int mi355_solve(mi355_factor *F, int sys, int64_t nrhs, const double *B, int64_t ldb, double *X, int64_t ldx)
+{
+    if (!F) return fail(MI355_INVALID, "null factor handle");
+    return mi355_solve_x(F, sys, nrhs, F->E == 2 ? MI355_COMPLEX : MI355_REAL, B, ldb, X, ldx);
 }
 
 double *mi355_factor_device_Lx(mi355_factor *F) { return F ? F->Lx.p : nullptr; }

@@ -150,38 +150,100 @@ __device__ __forceinline__ double wave_colsum8(double (&v)[8], int lane)
 // lane = row, wave w owns columns [16w, 16w+16) (a wave without columns leaves at once: most
 // supernodes are narrower than 16); the 64-lane sums are formed with two transpose-reduces per
 // rhs, lanes 0..7 issue the atomics.
+// NRA > 0 (nrhs <= NRA <= SOLVE_NR): one workgroup walks `group` consecutive entries of the tile table and keeps
+// its partial sums in registers while the entries belong to the same 64-column block, so a tall block
+// (tens of thousands of rows under 64 columns, hundreds of tiles that all add into the same 64 x nrhs
+// entries of X) sends one set of atomics per workgroup instead of one per tile.
+template <int NRA>
 __global__ __launch_bounds__(256) void k_solve_bwd_update(
-    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, const double *__restrict__ Lx,
-    const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
 {
-    const PotrfTask t = tasks[tile_task[blockIdx.x]];
-    const int tid = threadIdx.x, nb = t.nb;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    if (w * 16 >= nb) return;                       // no barrier in this kernel
-    const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + lane;
-    const bool ok = r < t.lda;
-    const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
-    double *__restrict__ x1 = X + t.k1 + t.col0;
-    double l[16];
+    if constexpr (NRA == 0) {
+        const PotrfTask t = tasks[tile_task[blockIdx.x]];
+        const int nb = t.nb;
+        if (w * 16 >= nb) return;                       // no barrier in this kernel
+        const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + lane;
+        const bool ok = r < t.lda;
+        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+        double *__restrict__ x1 = X + t.k1 + t.col0;
+        double l[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int c = w * 16 + q;
-        l[q] = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
-    }
-    int64_t row = 0;
-    if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
-    for (int j = 0; j < nrhs; j++) {
-        const double xr = ok ? X[row + (int64_t)j * ldx] : 0.0;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            if (w * 16 + half * 8 >= nb) break;     // wave-uniform
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = l[half * 8 + q] * xr;
-            const double s = wave_colsum8(v, lane);
-            const int c = w * 16 + half * 8 + lane;
-            if (lane < 8 && c < nb) atomic_add_f64(x1 + c + (int64_t)j * ldx, -s);
+        for (int q = 0; q < 16; q++) {
+            const int c = w * 16 + q;
+            l[q] = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
         }
+        int64_t row = 0;
+        if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+        for (int j = 0; j < nrhs; j++) {
+            const double xr = ok ? X[row + (int64_t)j * ldx] : 0.0;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (w * 16 + half * 8 >= nb) break;     // wave-uniform
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = l[half * 8 + q] * xr;
+                const double s = wave_colsum8(v, lane);
+                const int c = w * 16 + half * 8 + lane;
+                if (lane < 8 && c < nb) atomic_add_f64(x1 + c + (int64_t)j * ldx, -s);
+            }
+        }
+    } else {
+        const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
+        double acc[NRA][16];
+#pragma unroll
+        for (int j = 0; j < NRA; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[j][q] = 0.0;
+        int cur = -1;
+        PotrfTask t = tasks[tile_task[e0]];
+        auto flush = [&]() {
+            const int nb = t.nb;
+            if (w * 16 >= nb) return;
+            double *__restrict__ x1 = X + t.k1 + t.col0;
+#pragma unroll
+            for (int j = 0; j < NRA; j++) {
+                if (j >= nrhs) break;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    if (w * 16 + half * 8 >= nb) break;
+                    double v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { v[q] = acc[j][half * 8 + q]; acc[j][half * 8 + q] = 0.0; }
+                    const double s = wave_colsum8(v, lane);
+                    const int c = w * 16 + half * 8 + lane;
+                    if (lane < 8 && c < nb) atomic_add_f64(x1 + c + (int64_t)j * ldx, -s);
+                }
+            }
+        };
+        for (int64_t e = e0; e < e1; e++) {
+            const int ti = tile_task[e];
+            if (ti != cur) {
+                if (cur >= 0) flush();
+                cur = ti;
+                t = tasks[ti];
+            }
+            const int nb = t.nb;
+            if (w * 16 >= nb) continue;                 // wave-uniform
+            const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + lane;
+            const bool ok = r < t.lda;
+            const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+            int64_t row = 0;
+            if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+            double xr[NRA];
+#pragma unroll
+            for (int j = 0; j < NRA; j++) xr[j] = (ok && j < nrhs) ? X[row + (int64_t)j * ldx] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = w * 16 + q;
+                const double l = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NRA; j++) acc[j][q] += l * xr[j];
+            }
+        }
+        if (cur >= 0) flush();
     }
 }
 

@@ -35,7 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
-    "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev",
+    "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
 ]
 
 _LIB = None
@@ -73,6 +73,9 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.mi355_factor_set_perm.argtypes = [C.c_void_p, C.c_void_p]
         L.mi355_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, _f64p, C.c_int64, _f64p, C.c_int64]
+        L.mi355_solve_x.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, _f64p, C.c_int64, _f64p, C.c_int64]
+        L.mi355_solve_x_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int64]
         L.mi355_solve_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.mi355_factor_device_Lx.argtypes = [C.c_void_p]
         L.mi355_factor_device_Lx.restype = C.c_void_p
@@ -246,20 +249,21 @@ class SupernodalFactor:
 
     def solve(self, B, sys=0):
         """cholmod_solve(sys, L, B) for the supernodal factor: sys = CHOLMOD_A (0) ... CHOLMOD_Pt (8);
-        permutations and sweeps run on the device (cholmod_solve.c:656-717)."""
-        dt = np.complex128 if self.E == 2 else np.float64
-        if self.E == 1 and np.iscomplexobj(B):
-            raise Mi355Error(CHOLMOD_INVALID, "L and B must have the same xtype")
-        B = np.asarray(B, dtype=dt)
+        permutations and sweeps run on the device (cholmod_solve.c:656-717).  B may be real or complex
+        whatever L is; X is complex if either is (real L + complex B: the reference's "dual" path)."""
+        B = np.asarray(B)
+        bc = np.iscomplexobj(B)
+        xc = bc or self.E == 2
+        B = B.astype(np.complex128 if bc else np.float64)
         one_d = B.ndim == 1
         if one_d:
             B = B[:, None]
         n, nrhs = B.shape
-        bb = np.array(B.T, dtype=dt, order="C", copy=True)
-        xx = np.zeros_like(bb)
+        bb = np.array(B.T, order="C", copy=True)
+        xx = np.zeros((nrhs, n), dtype=np.complex128 if xc else np.float64)
         if bb.size:
-            _check(lib().mi355_solve(self._h, int(sys), nrhs, bb.view(np.float64).reshape(-1), n,
-                                     xx.view(np.float64).reshape(-1), n))
+            _check(lib().mi355_solve_x(self._h, int(sys), nrhs, 2 if bc else 1, bb.view(np.float64).reshape(-1), n,
+                                       xx.view(np.float64).reshape(-1), n))
         out = xx.T.copy()
         return out[:, 0] if one_d else out
 

@@ -381,6 +381,12 @@ def test_solve_with_permutation_vs_reference(engine, kind, size, nrhs, have_ref)
     Z = np.empty_like(B)
     Z[perm] = B
     assert np.array_equal(L.solve(B, 8), Z)              # Pt: x = P' b
+    # real L, complex B: the reference's "dual" path (cholmod_solve.c:668) = two real solves
+    Bc = B + 1j * B[::-1]
+    Xc = L.solve(Bc, 0)
+    assert np.iscomplexobj(Xc)
+    assert relerr(Xc, L.solve(Bc.real.copy(), 0) + 1j * L.solve(Bc.imag.copy(), 0)) < 1e-13
+    assert np.array_equal(L.solve(Bc, 7), Bc[perm])
     # natural ordering after set_perm(None)
     L.set_perm(None)
     assert relerr(L.solve(B, 0), L.super_ltsolve(Yl)) < 1e-12
@@ -408,3 +414,5 @@ def test_solve_complex_with_permutation(engine, have_ref):
     rng = np.random.default_rng(3)
     B = rng.standard_normal((p["n"], 3)) + 1j * rng.standard_normal((p["n"], 3))
     assert relerr(L.solve(B, 0), r.solve(B)) < 1e-9
+    Br = rng.standard_normal((p["n"], 2))                      # complex L, real B: zero imaginary part on the way in
+    assert relerr(L.solve(Br, 0), L.solve(Br + 0j, 0)) < 1e-14
