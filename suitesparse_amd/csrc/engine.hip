@@ -608,12 +608,26 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
-            hipLaunchKernelGGL(cplx ? k_solve_diag_c<false> : k_solve_diag<false>, dim3((unsigned)st.count), dim3(256),
-                               0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
-            if (st.stiles > 0)
-                hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
-                                   dim3(cplx ? SOLVE_ROWS : 256), 0, F->stream,
-                                   P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+            if (!cplx && nr >= SOLVE_MMA_MIN)
+                hipLaunchKernelGGL(k_solve_diag_mma<false>, dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            else
+                hipLaunchKernelGGL(cplx ? k_solve_diag_c<false> : k_solve_diag<false>, dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            if (st.stiles > 0) {
+                if (!cplx && nr >= SOLVE_MMA_MIN) {
+                    const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+                    const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
+                    for (int j0 = 0; j0 < nr; j0 += 64)
+                        hipLaunchKernelGGL(k_solve_fwd_mma, dim3(grid), dim3(256), 0, F->stream,
+                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nr, j0);
+                } else {
+                    hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
+                                       dim3(cplx ? SOLVE_ROWS : 256), 0, F->stream,
+                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+                }
+            }
             HIP_TRY(hipGetLastError());
         }
     } else {
@@ -624,6 +638,13 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                 if (cplx) {
                     hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
                                        P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+                } else if (nr >= SOLVE_MMA_MIN) {
+                    const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 256));
+                    const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
+                    for (int j0 = 0; j0 < nr; j0 += 64)
+                        hipLaunchKernelGGL(k_solve_bwd_mma, dim3(grid), dim3(256), 0, F->stream,
+                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nr, j0);
                 } else if (nr <= SOLVE_NR) {
                     // a workgroup walks `group` table entries: fewer atomics into the same 64 x nrhs entries of a
                     // tall block, while at least ~128 workgroups stay per launch
@@ -643,8 +664,12 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                        F->Lx.p, F->dLs.p, X, d, nr);
                 }
             }
-            hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
-                               0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            if (!cplx && nr >= SOLVE_MMA_MIN)
+                hipLaunchKernelGGL(k_solve_diag_mma<true>, dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            else
+                hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             HIP_TRY(hipGetLastError());
         }
     }

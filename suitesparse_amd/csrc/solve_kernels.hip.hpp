@@ -111,12 +111,18 @@ __global__ __launch_bounds__(256) void k_solve_fwd_update(
         for (int j = 0; j < SOLVE_NR; j++) red[w][rl][j] = acc[j];
         __syncthreads();
         if (w == 0 && ok) {
-            const int64_t row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+            // rows inside the supernode's own column range are written by this block alone in this launch
+            // (any other writer would be a descendant, i.e. on a lower level): plain read-modify-write;
+            // rows of ancestors can be hit by several supernodes of the level at once: atomics
+            const bool own = r < t.nscol;
+            const int64_t row = own ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
 #pragma unroll
             for (int j = 0; j < SOLVE_NR; j++)
-                if (j < nj)
-                    atomic_add_f64(X + row + (int64_t)(j0 + j) * ldx,
-                                   -(red[0][rl][j] + red[1][rl][j] + red[2][rl][j] + red[3][rl][j]));
+                if (j < nj) {
+                    const double v = red[0][rl][j] + red[1][rl][j] + red[2][rl][j] + red[3][rl][j];
+                    double *xp = X + row + (int64_t)(j0 + j) * ldx;
+                    if (own) *xp -= v; else atomic_add_f64(xp, -v);
+                }
         }
     }
 }
@@ -244,6 +250,225 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
             }
         }
         if (cur >= 0) flush();
+    }
+}
+
+//------------------------------------------------------------------------------
+// Multi-right-hand-side sweeps on the FP64 MFMA pipe (real L, nrhs >= SOLVE_MMA_MIN).
+// With many right-hand sides the off-diagonal parts are GEMMs (64 columns of L against 64 x nrhs of X):
+// 16 flop per byte of L at nrhs = 64, i.e. past the HBM roofline and onto the matrix pipe.  Both kernels
+// walk `group` consecutive entries of the tile table (64 rows of one 64-column block each), handle up to
+// 64 right-hand sides [j0, j0+64) per launch, and put the rows of X along the lanes of the result so
+// that loads, stores and atomics touch runs of 16 consecutive doubles.
+//------------------------------------------------------------------------------
+constexpr int SOLVE_MMA_MIN = 8;
+constexpr int SM_LD = 66;            // LDS row stride in doubles: 16 rows x 4 k land on disjoint banks
+
+// forward: X[row(r)][j] -= sum_c L[r][col0+c] * x1[c][j].  Contraction over the 64 columns: L is read straight
+// from global memory in MFMA operand layout (16 consecutive rows per k: 128-byte runs, every entry of the
+// tile read once by exactly one wave); x1 (shared by all tiles of the block) is staged in LDS once per block.
+__global__ __launch_bounds__(256) void k_solve_fwd_mma(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx,
+    int nrhs, int j0)
+{
+    __shared__ double Xs[64][SM_LD];                     // Xs[j][c] = x1[c][j0 + j]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nj = min(64, nrhs - j0);
+    const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
+    int cur = -1;
+    PotrfTask t = tasks[tile_task[e0]];
+    for (int64_t e = e0; e < e1; e++) {
+        const int ti = tile_task[e];
+        if (ti != cur) {
+            cur = ti;
+            t = tasks[ti];
+            __syncthreads();                             // readers of the previous block's x1 are done
+            const double *__restrict__ x1 = X + t.k1 + t.col0;
+            const int njp = (nj + 15) & ~15;            // operand rows read: whole 16-blocks of right-hand sides
+            for (int idx = tid; idx < 64 * njp; idx += 256) {
+                const int c = idx & 63, j = idx >> 6;
+                Xs[j][c] = (c < t.nb && j < nj) ? x1[c + (int64_t)(j0 + j) * ldx] : 0.0;
+            }
+            __syncthreads();
+        }
+        const int nb = t.nb;
+        const int nq = (nb + 3) >> 2;                    // k-steps of 4 columns that hold anything
+        const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + w * 16 + l15;      // row inside s
+        const bool ok = r < t.lda;
+        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+        double bl[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = 4 * q + l4;
+            bl[q] = (q < nq) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;   // c >= nb: finite value against a zero of Xs
+        }
+        v4d acc[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (q >= nq) break;                                      // uniform
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+                if (16 * jb >= nj) break;                            // uniform
+                acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 * jb + l15][4 * q + l4], bl[q], acc[jb], 0, 0, 0);
+            }
+        }
+        if (ok) {
+            // own rows (inside the supernode's column range): this block is their only writer in this launch
+            const bool own = r < t.nscol;
+            const int64_t row = own ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+            if (own) {
+                double xv[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int j = 16 * (q >> 2) + l4 + 4 * (q & 3);  // D row = rhs, D column (lane%16) = row of X
+                    xv[q] = (j < nj) ? X[row + (int64_t)(j0 + j) * ldx] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int j = 16 * (q >> 2) + l4 + 4 * (q & 3);
+                    if (j < nj) X[row + (int64_t)(j0 + j) * ldx] = xv[q] - acc[q >> 2][q & 3];
+                }
+            } else {
+#pragma unroll
+                for (int jb = 0; jb < 4; jb++) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int j = 16 * jb + l4 + 4 * g;
+                        if (j < nj) atomic_add_f64(X + row + (int64_t)(j0 + j) * ldx, -acc[jb][g]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// backward: x1[c][j] -= sum_r L[r][col0+c] * X[row(r)][j].  Contraction over the rows: the L tile and the
+// gathered rows of X are staged in LDS (coalesced along the rows) and read back in operand layout; the
+// products of all the tiles a workgroup walks accumulate in the MFMA registers while the block stays the
+// same, so a tall block sends one set of atomics per workgroup.
+__global__ __launch_bounds__(256) void k_solve_bwd_mma(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx,
+    int nrhs, int j0)
+{
+    __shared__ double Lt[64][SM_LD];                     // Lt[c][r]
+    __shared__ double Xt[64][SM_LD];                     // Xt[j][r]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nj = min(64, nrhs - j0);
+    const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
+    v4d acc[4];                                          // wave w: columns c in [16w, 16w+16), rhs block jb
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int cur = -1;
+    PotrfTask t = tasks[tile_task[e0]];
+    auto flush = [&]() {
+        double *__restrict__ x1 = X + t.k1 + t.col0;
+        const int c = 16 * w + l15;                      // D column (lane%16) = column of the block
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int j = 16 * jb + l4 + 4 * g;
+                if (c < t.nb && j < nj) atomic_add_f64(x1 + c + (int64_t)(j0 + j) * ldx, -acc[jb][g]);
+                acc[jb][g] = 0.0;
+            }
+        }
+    };
+    for (int64_t e = e0; e < e1; e++) {
+        const int ti = tile_task[e];
+        if (ti != cur) {
+            if (cur >= 0) flush();
+            cur = ti;
+            t = tasks[ti];
+        }
+        const int nb = t.nb;
+        const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + lane;
+        const bool ok = r < t.lda;
+        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+        int64_t row = 0;
+        if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+        __syncthreads();                                 // the previous tile's operand reads are done
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int c = w * 16 + q;
+            Lt[c][lane] = (ok && c < nb) ? Lr[(int64_t)c * t.lda] : 0.0;
+            const int j = w * 16 + q;
+            Xt[j][lane] = (ok && j < nj) ? X[row + (int64_t)(j0 + j) * ldx] : 0.0;
+        }
+        __syncthreads();
+        if (16 * w < nb) {                               // wave-uniform; no barrier inside
+            const int rows_here = min(SOLVE_ROWS, t.lda - (t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS));
+            const int nq = (rows_here + 3) >> 2;         // k-steps of 4 rows that hold anything (the rest is zero)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if (q >= nq) break;
+                const double bl = Lt[16 * w + l15][4 * q + l4];
+#pragma unroll
+                for (int jb = 0; jb < 4; jb++) {
+                    if (16 * jb >= nj) break;
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xt[16 * jb + l15][4 * q + l4], bl, acc[jb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (cur >= 0) flush();
+}
+
+// x1 <- inv(L11) x1 (TRANS = false) or inv(L11)^T x1 (TRANS = true) for many right-hand sides: a 64 x 64 x nrhs
+// product per block on the MFMA pipe.  One workgroup per block; wave w owns rows [16w, 16w+16) of the result.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_solve_diag_mma(
+    const PotrfTask *__restrict__ tasks, const double *__restrict__ Dinv,
+    double *__restrict__ X, int64_t ldx, int nrhs)
+{
+    __shared__ double Ds[64][SM_LD];                     // Ds[i][k] = D(i,k), or D(k,i) when TRANS
+    __shared__ double Xs[64][SM_LD];                     // Xs[j][k] = x1[k][j0 + j]
+    const PotrfTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nb = t.nb;
+    const double *__restrict__ D = Dinv + t.dinv_off;
+    double *__restrict__ x1 = X + t.k1 + t.col0;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx & 63, k = idx >> 6;            // D is column-major, ld nb: consecutive threads read a column
+        const double v = (i < nb && k < nb) ? D[i + k * nb] : 0.0;
+        if (TRANS) Ds[k][i] = v; else Ds[i][k] = v;
+    }
+    const int nq = (nb + 3) >> 2;
+    for (int j0 = 0; j0 < nrhs; j0 += 64) {
+        const int nj = min(64, nrhs - j0), njp = (nj + 15) & ~15;
+        __syncthreads();                                 // Ds filled / previous chunk's reads and writes done
+        for (int idx = tid; idx < 64 * njp; idx += 256) {
+            const int k = idx & 63, j = idx >> 6;
+            Xs[j][k] = (k < nb && j < nj) ? x1[k + (int64_t)(j0 + j) * ldx] : 0.0;
+        }
+        __syncthreads();
+        if (16 * w < nb) {
+            v4d acc[4];
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if (q >= nq) break;
+                const double bl = Ds[16 * w + l15][4 * q + l4];
+#pragma unroll
+                for (int jb = 0; jb < 4; jb++) {
+                    if (16 * jb >= nj) break;
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 * jb + l15][4 * q + l4], bl, acc[jb], 0, 0, 0);
+                }
+            }
+            const int i = 16 * w + l15;                  // D column (lane%16) = row of the block
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int j = 16 * jb + l4 + 4 * g;
+                    if (i < nb && j < nj) x1[i + (int64_t)(j0 + j) * ldx] = acc[jb][g];
+                }
+            }
+        }
     }
 }
 

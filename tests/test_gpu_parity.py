@@ -416,3 +416,33 @@ def test_solve_complex_with_permutation(engine, have_ref):
     assert relerr(L.solve(B, 0), r.solve(B)) < 1e-9
     Br = rng.standard_normal((p["n"], 2))                      # complex L, real B: zero imaginary part on the way in
     assert relerr(L.solve(Br, 0), L.solve(Br + 0j, 0)) < 1e-14
+
+
+@pytest.mark.parametrize("kind,size,nrhs", [("lap3d", 20, 8), ("lap3d", 20, 23), ("lap2d", 90, 64), ("elast", 8, 70),
+                                            ("lap3d", 28, 130)])
+def test_multi_rhs_solve_on_mfma(engine, kind, size, nrhs, have_ref):
+    """nrhs >= 8 routes the off-diagonal parts of both sweeps to the MFMA kernels (k_solve_fwd_mma /
+    k_solve_bwd_mma; chunks of 64 right-hand sides, ragged last chunk): against the reference's sweeps."""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d,
+         "elast": problems.elasticity27}[kind](size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    sym = r.symbolic()
+    L = engine.SupernodalFactor(sym)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    rng = np.random.default_rng(nrhs)
+    B = rng.standard_normal((p["n"], nrhs))
+    Yg, Yr = L.super_lsolve(B), r.super_solve(B, True)
+    assert relerr(Yg, Yr) < 1e-9
+    Xg, Xr = L.super_ltsolve(Yr), r.super_solve(Yr, False)
+    assert relerr(Xg, Xr) < 1e-9
+    # column j of a multi-RHS solve equals the single-RHS solve of that column (same kernels or not)
+    j = nrhs // 2
+    assert relerr(L.super_ltsolve(L.super_lsolve(B[:, j])), L.super_ltsolve(L.super_lsolve(B))[:, j]) < 1e-10
