@@ -90,6 +90,8 @@ struct mi355_factor_s {
     DevBuf<int64_t> dPerm;                 // L->Perm for mi355_solve (empty: identity)
     DevBuf<double> Ywork;                  // n x nrhs workspace of mi355_solve (grown on demand)
     size_t ywork_cap = 0;
+    DevBuf<double> Yrow;                   // row-major image of the right-hand sides for the MFMA sweeps
+    size_t yrow_cap = 0;
     DevBuf<int32_t> dLs, dSupermap;
     DevBuf<int64_t> dSuper, dLpi, dLpx;
     DevBuf<int> info;           // nsuper + 2 (first-failure scratch at [nsuper], [nsuper+1])
@@ -604,18 +606,38 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     HIP_TRY(hipEventRecord(e0, F->stream));
     const int nr = (int)nrhs;
     const bool cplx = F->E == 2;
+    // many right-hand sides: the MFMA sweeps run on a row-major image (solve_kernels.hip.hpp); X and d then
+    // name that image and its leading dimension until the transpose back
+    double *const Xcol = X;
+    const int64_t dcol = d;
+    const bool mma = !cplx && nr >= tuning().solve_mma_min;
+    if (mma) {
+        const int64_t ldr = (nrhs + 15) & ~(int64_t)15;
+        const size_t need = (size_t)S.n * (size_t)ldr;
+        if (need > F->yrow_cap) {
+            F->Yrow.release();
+            F->yrow_cap = 0;
+            HIP_TRY(F->Yrow.alloc(need));
+            F->yrow_cap = need;
+        }
+        hipLaunchKernelGGL(k_solve_transpose, dim3((unsigned)((S.n + 63) / 64)), dim3(256), 0, F->stream,
+                           S.n, nr, Xcol, dcol, F->Yrow.p, ldr, 1);
+        HIP_TRY(hipGetLastError());
+        X = F->Yrow.p;
+        d = ldr;
+    }
     if (lower) {
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
-            if (!cplx && nr >= SOLVE_MMA_MIN)
+            if (!cplx && nr >= tuning().solve_mma_min)
                 hipLaunchKernelGGL(k_solve_diag_mma<false>, dim3((unsigned)st.count), dim3(256),
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             else
                 hipLaunchKernelGGL(cplx ? k_solve_diag_c<false> : k_solve_diag<false>, dim3((unsigned)st.count), dim3(256),
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             if (st.stiles > 0) {
-                if (!cplx && nr >= SOLVE_MMA_MIN) {
+                if (!cplx && nr >= tuning().solve_mma_min) {
                     const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
                     for (int j0 = 0; j0 < nr; j0 += 64)
@@ -638,8 +660,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                 if (cplx) {
                     hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
                                        P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
-                } else if (nr >= SOLVE_MMA_MIN) {
-                    const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 256));
+                } else if (nr >= tuning().solve_mma_min) {
+                    const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
                     for (int j0 = 0; j0 < nr; j0 += 64)
                         hipLaunchKernelGGL(k_solve_bwd_mma, dim3(grid), dim3(256), 0, F->stream,
@@ -664,7 +686,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                        F->Lx.p, F->dLs.p, X, d, nr);
                 }
             }
-            if (!cplx && nr >= SOLVE_MMA_MIN)
+            if (!cplx && nr >= tuning().solve_mma_min)
                 hipLaunchKernelGGL(k_solve_diag_mma<true>, dim3((unsigned)st.count), dim3(256),
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             else
@@ -672,6 +694,11 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             HIP_TRY(hipGetLastError());
         }
+    }
+    if (mma) {
+        hipLaunchKernelGGL(k_solve_transpose, dim3((unsigned)((S.n + 63) / 64)), dim3(256), 0, F->stream,
+                           S.n, nr, Xcol, dcol, F->Yrow.p, d, 0);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, F->stream));
     HIP_TRY(hipEventSynchronize(e1));
@@ -917,6 +944,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 6) tuning().stagger = value;
     else if (key == 7) tuning().ob2 = value;
     else if (key == 8) tuning().ob3 = value;
+    else if (key == 9) tuning().solve_mma_min = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

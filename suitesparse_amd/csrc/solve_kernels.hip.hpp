@@ -254,22 +254,46 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
 }
 
 //------------------------------------------------------------------------------
-// Multi-right-hand-side sweeps on the FP64 MFMA pipe (real L, nrhs >= SOLVE_MMA_MIN).
+// Multi-right-hand-side sweeps on the FP64 MFMA pipe (real L, nrhs >= Tuning::solve_mma_min).
 // With many right-hand sides the off-diagonal parts are GEMMs (64 columns of L against 64 x nrhs of X):
-// 16 flop per byte of L at nrhs = 64, i.e. past the HBM roofline and onto the matrix pipe.  Both kernels
-// walk `group` consecutive entries of the tile table (64 rows of one 64-column block each), handle up to
-// 64 right-hand sides [j0, j0+64) per launch, and put the rows of X along the lanes of the result so
-// that loads, stores and atomics touch runs of 16 consecutive doubles.
+// 16 flop per byte of L at nrhs = 64, i.e. past the HBM roofline and onto the matrix pipe.
+// These kernels work on a ROW-MAJOR image Y of the right-hand sides (entry (row, j) at Y[row*ldr + j]): the
+// 64 x nrhs block of X that a tile touches is then 64 runs of nrhs consecutive doubles instead of
+// 64 x nrhs doubles spread over nrhs columns that lie n*8 bytes apart (27 MB at 150^3: one TLB entry and
+// one DRAM page per right-hand side and tile).  The engine transposes on the way in and out.
+// Each kernel walks `group` consecutive entries of the tile table (64 rows of one 64-column block each)
+// and handles up to 64 right-hand sides [j0, j0+64) per launch; the right-hand sides run along lane%16 of
+// the MFMA result, so stores and atomics touch runs of 16 consecutive doubles.
 //------------------------------------------------------------------------------
-constexpr int SOLVE_MMA_MIN = 8;
 constexpr int SM_LD = 66;            // LDS row stride in doubles: 16 rows x 4 k land on disjoint banks
 
-// forward: X[row(r)][j] -= sum_c L[r][col0+c] * x1[c][j].  Contraction over the 64 columns: L is read straight
+// Y (row-major, ld ldr) <- X (column-major, ld ldx) or back; 64 x 64 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void k_solve_transpose(int64_t n, int nrhs, double *__restrict__ Xc, int64_t ldx,
+                                                         double *__restrict__ Yr, int64_t ldr, int to_rowmajor)
+{
+    __shared__ double T[64][65];
+    const int tid = threadIdx.x, a = tid & 63, b4 = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int j0 = 0; j0 < nrhs; j0 += 64) {
+        __syncthreads();
+        for (int b = b4; b < 64; b += 4) {
+            if (to_rowmajor) { if (r0 + a < n && j0 + b < nrhs) T[b][a] = Xc[r0 + a + (int64_t)(j0 + b) * ldx]; }   // T[j][r]
+            else             { if (r0 + b < n && j0 + a < nrhs) T[a][b] = Yr[(r0 + b) * ldr + j0 + a]; }            // T[j][r]
+        }
+        __syncthreads();
+        for (int b = b4; b < 64; b += 4) {
+            if (to_rowmajor) { if (r0 + b < n && j0 + a < nrhs) Yr[(r0 + b) * ldr + j0 + a] = T[a][b]; }
+            else             { if (r0 + a < n && j0 + b < nrhs) Xc[r0 + a + (int64_t)(j0 + b) * ldx] = T[b][a]; }
+        }
+    }
+}
+
+// forward: Y[row(r)][j] -= sum_c L[r][col0+c] * x1[c][j].  Contraction over the 64 columns: L is read straight
 // from global memory in MFMA operand layout (16 consecutive rows per k: 128-byte runs, every entry of the
 // tile read once by exactly one wave); x1 (shared by all tiles of the block) is staged in LDS once per block.
 __global__ __launch_bounds__(256) void k_solve_fwd_mma(
     const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
-    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrhs, int j0)
 {
     __shared__ double Xs[64][SM_LD];                     // Xs[j][c] = x1[c][j0 + j]
@@ -284,24 +308,25 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
             cur = ti;
             t = tasks[ti];
             __syncthreads();                             // readers of the previous block's x1 are done
-            const double *__restrict__ x1 = X + t.k1 + t.col0;
-            const int njp = (nj + 15) & ~15;            // operand rows read: whole 16-blocks of right-hand sides
-            for (int idx = tid; idx < 64 * njp; idx += 256) {
-                const int c = idx & 63, j = idx >> 6;
-                Xs[j][c] = (c < t.nb && j < nj) ? x1[c + (int64_t)(j0 + j) * ldx] : 0.0;
+            const double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr + j0;
+            for (int idx = tid; idx < 64 * t.nb; idx += 256) {
+                const int j = idx & 63, c = idx >> 6;    // consecutive threads: consecutive right-hand sides
+                Xs[j][c] = (j < nj) ? x1[(int64_t)c * ldr + j] : 0.0;
             }
+            for (int idx = tid; idx < 64 * (((t.nb + 3) & ~3) - t.nb); idx += 256)       // zero the k padding
+                Xs[idx & 63][t.nb + (idx >> 6)] = 0.0;
             __syncthreads();
         }
         const int nb = t.nb;
         const int nq = (nb + 3) >> 2;                    // k-steps of 4 columns that hold anything
-        const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + w * 16 + l15;      // row inside s
-        const bool ok = r < t.lda;
-        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
-        double bl[16];
+        const int rbase = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + w * 16;       // first row of this wave
+        const int r = rbase + l15;                       // operand row of this lane
+        const double *__restrict__ Lr = Lx + t.a_off + ((r < t.lda ? r : t.col0) - t.col0);
+        double al[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = 4 * q + l4;
-            bl[q] = (q < nq) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;   // c >= nb: finite value against a zero of Xs
+            al[q] = (q < nq) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;   // c >= nb: finite value against a zero of Xs
         }
         v4d acc[4];
 #pragma unroll
@@ -312,67 +337,58 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
 #pragma unroll
             for (int jb = 0; jb < 4; jb++) {
                 if (16 * jb >= nj) break;                            // uniform
-                acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 * jb + l15][4 * q + l4], bl[q], acc[jb], 0, 0, 0);
+                acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], Xs[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
             }
         }
-        if (ok) {
-            // own rows (inside the supernode's column range): this block is their only writer in this launch
-            const bool own = r < t.nscol;
-            const int64_t row = own ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
-            if (own) {
-                double xv[16];
+        // result: rows rbase + lane/16 + 4g (g = 0..3), right-hand side 16 jb + lane%16
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int j = 16 * (q >> 2) + l4 + 4 * (q & 3);  // D row = rhs, D column (lane%16) = row of X
-                    xv[q] = (j < nj) ? X[row + (int64_t)(j0 + j) * ldx] : 0.0;
-                }
+        for (int g = 0; g < 4; g++) {
+            const int rr = rbase + l4 + 4 * g;
+            if (rr >= t.lda) continue;
+            // rows inside the supernode's own column range are written by this block alone in this launch
+            // (any other writer would be a descendant, i.e. on a lower level): plain read-modify-write;
+            // rows of ancestors can be hit by several supernodes of the level at once: atomics
+            const bool own = rr < t.nscol;
+            const int64_t row = own ? (int64_t)t.k1 + rr : (int64_t)Ls[t.ls_off + rr];
+            double *__restrict__ yp = Y + row * ldr + j0 + l15;
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int j = 16 * (q >> 2) + l4 + 4 * (q & 3);
-                    if (j < nj) X[row + (int64_t)(j0 + j) * ldx] = xv[q] - acc[q >> 2][q & 3];
-                }
-            } else {
-#pragma unroll
-                for (int jb = 0; jb < 4; jb++) {
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int j = 16 * jb + l4 + 4 * g;
-                        if (j < nj) atomic_add_f64(X + row + (int64_t)(j0 + j) * ldx, -acc[jb][g]);
-                    }
+            for (int jb = 0; jb < 4; jb++) {
+                if (16 * jb + l15 < nj) {
+                    if (own) yp[16 * jb] -= acc[jb][g]; else atomic_add_f64(yp + 16 * jb, -acc[jb][g]);
                 }
             }
         }
     }
 }
 
-// backward: x1[c][j] -= sum_r L[r][col0+c] * X[row(r)][j].  Contraction over the rows: the L tile and the
-// gathered rows of X are staged in LDS (coalesced along the rows) and read back in operand layout; the
-// products of all the tiles a workgroup walks accumulate in the MFMA registers while the block stays the
-// same, so a tall block sends one set of atomics per workgroup.
+// backward: x1[c][j] -= sum_r L[r][col0+c] * Y[row(r)][j].  Contraction over the rows: the L tile and the
+// gathered rows of Y are staged in LDS and read back in operand layout; the products of all the tiles a
+// workgroup walks accumulate in the MFMA registers while the block stays the same, so a tall block sends
+// one set of atomics per workgroup.
 __global__ __launch_bounds__(256) void k_solve_bwd_mma(
     const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
-    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrhs, int j0)
 {
     __shared__ double Lt[64][SM_LD];                     // Lt[c][r]
     __shared__ double Xt[64][SM_LD];                     // Xt[j][r]
+    __shared__ int64_t rowof[64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int nj = min(64, nrhs - j0);
     const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
-    v4d acc[4];                                          // wave w: columns c in [16w, 16w+16), rhs block jb
+    v4d acc[4];                                          // wave w: columns c = 16w + lane/16 + 4g, rhs 16 jb + lane%16
 #pragma unroll
     for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
     int cur = -1;
     PotrfTask t = tasks[tile_task[e0]];
     auto flush = [&]() {
-        double *__restrict__ x1 = X + t.k1 + t.col0;
-        const int c = 16 * w + l15;                      // D column (lane%16) = column of the block
+        double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr + j0 + l15;
 #pragma unroll
-        for (int jb = 0; jb < 4; jb++) {
+        for (int g = 0; g < 4; g++) {
+            const int c = 16 * w + l4 + 4 * g;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int j = 16 * jb + l4 + 4 * g;
-                if (c < t.nb && j < nj) atomic_add_f64(x1 + c + (int64_t)(j0 + j) * ldx, -acc[jb][g]);
+            for (int jb = 0; jb < 4; jb++) {
+                if (c < t.nb && 16 * jb + l15 < nj) atomic_add_f64(x1 + (int64_t)c * ldr + 16 * jb, -acc[jb][g]);
                 acc[jb][g] = 0.0;
             }
         }
@@ -385,31 +401,34 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
             t = tasks[ti];
         }
         const int nb = t.nb;
-        const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + lane;
-        const bool ok = r < t.lda;
-        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
-        int64_t row = 0;
-        if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+        const int r0 = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS;
+        const int rows_here = min(SOLVE_ROWS, t.lda - r0);
+        const int r = r0 + lane;
+        const bool ok = lane < rows_here;
         __syncthreads();                                 // the previous tile's operand reads are done
+        if (w == 0) rowof[lane] = !ok ? 0 : (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
 #pragma unroll 4
         for (int q = 0; q < 16; q++) {
             const int c = w * 16 + q;
             Lt[c][lane] = (ok && c < nb) ? Lr[(int64_t)c * t.lda] : 0.0;
-            const int j = w * 16 + q;
-            Xt[j][lane] = (ok && j < nj) ? X[row + (int64_t)(j0 + j) * ldx] : 0.0;
+        }
+        __syncthreads();                                 // rowof visible
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int j = idx & 63, rr = idx >> 6;       // consecutive threads: consecutive right-hand sides
+            Xt[j][rr] = (rr < rows_here && j < nj) ? Y[rowof[rr] * ldr + j0 + j] : 0.0;
         }
         __syncthreads();
         if (16 * w < nb) {                               // wave-uniform; no barrier inside
-            const int rows_here = min(SOLVE_ROWS, t.lda - (t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS));
             const int nq = (rows_here + 3) >> 2;         // k-steps of 4 rows that hold anything (the rest is zero)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 if (q >= nq) break;
-                const double bl = Lt[16 * w + l15][4 * q + l4];
+                const double al = Lt[16 * w + l15][4 * q + l4];
 #pragma unroll
                 for (int jb = 0; jb < 4; jb++) {
                     if (16 * jb >= nj) break;
-                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xt[16 * jb + l15][4 * q + l4], bl, acc[jb], 0, 0, 0);
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al, Xt[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
                 }
             }
         }
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
 template <bool TRANS>
 __global__ __launch_bounds__(256) void k_solve_diag_mma(
     const PotrfTask *__restrict__ tasks, const double *__restrict__ Dinv,
-    double *__restrict__ X, int64_t ldx, int nrhs)
+    double *__restrict__ Y, int64_t ldr, int nrhs)
 {
     __shared__ double Ds[64][SM_LD];                     // Ds[i][k] = D(i,k), or D(k,i) when TRANS
     __shared__ double Xs[64][SM_LD];                     // Xs[j][k] = x1[k][j0 + j]
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int nb = t.nb;
     const double *__restrict__ D = Dinv + t.dinv_off;
-    double *__restrict__ x1 = X + t.k1 + t.col0;
+    double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int i = idx & 63, k = idx >> 6;            // D is column-major, ld nb: consecutive threads read a column
         const double v = (i < nb && k < nb) ? D[i + k * nb] : 0.0;
@@ -438,11 +457,11 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
     }
     const int nq = (nb + 3) >> 2;
     for (int j0 = 0; j0 < nrhs; j0 += 64) {
-        const int nj = min(64, nrhs - j0), njp = (nj + 15) & ~15;
+        const int nj = min(64, nrhs - j0);
         __syncthreads();                                 // Ds filled / previous chunk's reads and writes done
-        for (int idx = tid; idx < 64 * njp; idx += 256) {
-            const int k = idx & 63, j = idx >> 6;
-            Xs[j][k] = (k < nb && j < nj) ? x1[k + (int64_t)(j0 + j) * ldx] : 0.0;
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int j = idx & 63, k = idx >> 6;
+            Xs[j][k] = (k < nb && j < nj) ? x1[(int64_t)k * ldr + j0 + j] : 0.0;
         }
         __syncthreads();
         if (16 * w < nb) {
@@ -452,21 +471,19 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 if (q >= nq) break;
-                const double bl = Ds[16 * w + l15][4 * q + l4];
+                const double al = Ds[16 * w + l15][4 * q + l4];
 #pragma unroll
                 for (int jb = 0; jb < 4; jb++) {
                     if (16 * jb >= nj) break;
-                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 * jb + l15][4 * q + l4], bl, acc[jb], 0, 0, 0);
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al, Xs[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
                 }
             }
-            const int i = 16 * w + l15;                  // D column (lane%16) = row of the block
 #pragma unroll
-            for (int jb = 0; jb < 4; jb++) {
+            for (int g = 0; g < 4; g++) {
+                const int i = 16 * w + l4 + 4 * g;       // result row = lane/16 + 4g, right-hand side = lane%16
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int j = 16 * jb + l4 + 4 * g;
-                    if (i < nb && j < nj) x1[i + (int64_t)(j0 + j) * ldx] = acc[jb][g];
-                }
+                for (int jb = 0; jb < 4; jb++)
+                    if (i < nb && 16 * jb + l15 < nj) x1[(int64_t)i * ldr + j0 + 16 * jb + l15] = acc[jb][g];
             }
         }
     }

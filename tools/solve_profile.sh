@@ -10,7 +10,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace -d $O -o s -- python3 $R/bench.py -
 python3 - $O/s_results.db <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-for kn in ("k_solve_bwd_update", "k_solve_fwd_update", "k_solve_diag", "k_solve_fwd_mma", "k_solve_bwd_mma"):
+for kn in ("k_solve_diag", "k_solve_fwd_mma", "k_solve_bwd_mma", "k_solve_transpose"):
     rows = db.execute("select duration, grid_x, workgroup_x from kernels where name like ? order by duration desc", (f"%{kn}%",)).fetchall()
     tot = sum(r[0] for r in rows)
     print(f"{kn}: {len(rows)} launches, total {tot/1e6:.2f} ms")
