@@ -101,9 +101,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # rehearsal switches (a 1-GPU box can run the N>1 path with every rank on cuda:0 and gloo in place of RCCL)
+    if os.environ.get("MI355_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("MI355_BENCH_BACKEND", "nccl"))
     from suitesparse_amd import engine
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")

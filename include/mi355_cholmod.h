@@ -200,10 +200,11 @@ int mi355_debug_mfma_f64_rate(int device, double *out3);
  * (k_gemm64) or 1 (k_gemm128); kernel micro-benchmark for profiles/, no reference counterpart. */
 int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters, double *tflops);
 
-/* key 0: minimum M, key 1: minimum N of a task routed to the 128x128-tile kernel, key 2: outer
- * block width (affect factors created afterwards); key 3: retired; key 4: super-tile edge of the tile
- * order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks; key 6: start
- * stagger of k_gemm128 (experiment); key 7: second outer block width (0 = two blocking levels only). */
+/* Experiment switches (defaults are the measured best; they affect factors created afterwards):
+ * key 0 / 1: minimum M / N of a task routed to the 128x128-tile kernel; key 2, 7, 8: nested block widths of
+ * the panel factorization above the 64-column panels (defaults 256, 1024, none); key 4: super-tile edge of the
+ * tile order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks;
+ * key 9: fewest right-hand sides that run the solves on the MFMA kernels; keys 3 and 6: retired. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -241,7 +241,7 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                 hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles),
                                    dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
-                                   st.ntiles >= 1536 ? tuning().stagger : 0, (unsigned long long *)nullptr);
+                                   (unsigned long long *)nullptr);
             else
                 hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
@@ -941,7 +941,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 3) (void)value;                 // retired (4x4x4 MFMA variant)
     else if (key == 4) tuning().supertile = value;
     else if (key == 5) tuning().xcd_deal = value;
-    else if (key == 6) tuning().stagger = value;
+    else if (key == 6) (void)value;                 // retired (start stagger experiment)
     else if (key == 7) tuning().ob2 = value;
     else if (key == 8) tuning().ob3 = value;
     else if (key == 9) tuning().solve_mma_min = value;
@@ -992,7 +992,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
         if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
         if (kernel >= 1)
             hipLaunchKernelGGL(k_gemm128, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr,
-                               ntiles >= 1536 ? tuning().stagger : 0, dstamps.p);
+                               dstamps.p);
         else
             hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
     }

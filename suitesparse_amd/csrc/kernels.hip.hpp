@@ -91,23 +91,6 @@ __global__ __launch_bounds__(256) void k_relmap(
     if (pos < 0) { *err = 1; relmap[e] = 0; } else relmap[e] = pos;
 }
 
-//------------------------------------------------------------------------------
-// tile index -> (tm, tn) inside one task
-//------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_coords(int64_t t, int MT, int NT, int mode, int &tm, int &tn)
-{
-    if (mode == GEMM_OVERWRITE || MT < NT) { tm = (int)(t / NT); tn = (int)(t % NT); return; }
-    const int64_t tri = (int64_t)NT * (NT + 1) / 2;
-    if (t < tri) {
-        int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(r + 1) * (r + 2) / 2 <= t) r++;
-        while ((int64_t)r * (r + 1) / 2 > t) r--;
-        tm = r; tn = (int)(t - (int64_t)r * (r + 1) / 2);
-    } else {
-        const int64_t q = t - tri;
-        tm = NT + (int)(q / NT); tn = (int)(q % NT);
-    }
-}
 
 //------------------------------------------------------------------------------
 // k_gemm64: batched C = A * B^T on v_mfma_f64_16x16x4_f64, 64x64 tile per workgroup
@@ -254,7 +237,7 @@ constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row =>
 
 __global__ __launch_bounds__(256, 2) void k_gemm128(
     const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
-    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap, int stagger,
+    const double *__restrict__ Dinv, const int32_t *__restrict__ relmap,
     unsigned long long *__restrict__ stamps)       // debug builds of the micro-benchmark only: 4 clock stamps per tile
 {
     const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -277,16 +260,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     if (mode == GEMM_SCATTER_SUB) {
         if (tid < BTILE) rmM[tid] = (m0 + tid < M) ? relmap[t.rm_off + m0 + tid] : 0;
         else { int j = tid - BTILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
-    }
-
-    // All tiles of a launch take about the same time, so without help every workgroup of the chip reaches
-    // its read-modify-write epilogue at the same moment (HBM saturated, MFMA pipes idle) and then its main
-    // loop at the same moment (HBM idle).  The workgroups of the first round (two per CU) therefore start
-    // with a pseudo-random delay of up to one tile time, which spreads the phases for the whole launch.
-    if (stagger > 0 && bid < 512) {
-        const unsigned h = ((unsigned)bid * 2654435761u) >> 22;                   // 0..1023
-        const int units = (int)(((int64_t)((K + G128_KS - 1) / G128_KS) * stagger * h) >> 10);   // of 64*127 cycles
-        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(127);
     }
 
     const int lane = tid & 63, wave = tid >> 6;
