@@ -466,8 +466,10 @@ __global__ __launch_bounds__(256) void k_potrf64(
     const int64_t lda = t.lda;
     double *__restrict__ A = Lx + t.a_off;
 
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx & (NB - 1), j = idx >> 6;
+    const int nblk = (nb + 15) >> 4;                          // 16-column blocks that hold anything
+    const int np = nblk * 16;                                 // padded order: identity beyond nb
+    for (int idx = tid; idx < np * np; idx += 256) {
+        const int i = idx % np, j = idx / np;
         double v = (i == j) ? 1.0 : 0.0;                     // identity padding
         if (i < nb && j < nb) v = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
         Ls[i][j] = v;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void k_potrf64(
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     int fail_col = 0;                                         // wave 0 only: 1-based column of the first bad pivot
 #pragma unroll 1
-    for (int jb = 0; jb < 4; jb++) {
+    for (int jb = 0; jb < nblk; jb++) {
         const int c0 = 16 * jb;
         if (wave == 0) {
             // lane r (mod 16) holds row r of the diagonal block; entries right of the diagonal are never
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void k_potrf64(
         // TRSM: X_ib = A(ib,jb) * W^T for the block rows below (one per wave)
         {
             const int ib = jb + 1 + wave;
-            if (ib < 4) {
+            if (ib < nblk) {
                 v4d x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void k_potrf64(
         __syncthreads();
         // trailing update: A(ib,kb) -= X_ib X_kb^T for jb < kb <= ib < 4, block pairs dealt to the waves
         {
-            const int nrem = 3 - jb, npairs = nrem * (nrem + 1) / 2;
+            const int nrem = nblk - 1 - jb, npairs = nrem * (nrem + 1) / 2;
             for (int p = wave; p < npairs; p += 4) {
                 int ib = 0, q = p;
                 while (q > ib) { q -= ib + 1; ib++; }          // p -> (ib, q): q <= ib
@@ -547,17 +549,16 @@ __global__ __launch_bounds__(256) void k_potrf64(
     }
 
     if (tid == 0 && fail_col != 0 && info[t.s] == 0) info[t.s] = t.col0 + fail_col;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx & (NB - 1), j = idx >> 6;
-        if (i < nb && j < nb && i >= j) A[i + (int64_t)j * lda] = Ls[i][j];
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int i = idx % nb, j = idx / nb;
+        if (i >= j) A[i + (int64_t)j * lda] = Ls[i][j];
     }
 
     // off-diagonal blocks of the inverse, by distance d from the diagonal:
     // V(i,j) = -W_i * sum_{k=j}^{i-1} L(i,k) V(k,j); the sum's MFMA result registers are the B operand of W_i * (.)
-#pragma unroll
-    for (int d = 1; d < 4; d++) {
+    for (int d = 1; d < nblk; d++) {
         const int j = wave, i = wave + d;
-        if (i < 4) {
+        if (i < nblk) {
             v4d tsum = {0.0, 0.0, 0.0, 0.0};
             for (int k = j; k < i; k++) {
 #pragma unroll
