@@ -610,9 +610,10 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     // name that image and its leading dimension until the transpose back
     double *const Xcol = X;
     const int64_t dcol = d;
-    const bool mma = !cplx && nr >= tuning().solve_mma_min;
+    const bool mma = nr >= tuning().solve_mma_min;
+    const int nrr = nr * F->E;                          // real columns of the row-major image
     if (mma) {
-        const int64_t ldr = (nrhs + 15) & ~(int64_t)15;
+        const int64_t ldr = ((int64_t)nrr + 15) & ~(int64_t)15;
         const size_t need = (size_t)S.n * (size_t)ldr;
         if (need > F->yrow_cap) {
             F->Yrow.release();
@@ -620,8 +621,13 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             HIP_TRY(F->Yrow.alloc(need));
             F->yrow_cap = need;
         }
-        hipLaunchKernelGGL(k_solve_transpose, dim3((unsigned)((S.n + 63) / 64)), dim3(256), 0, F->stream,
-                           S.n, nr, Xcol, dcol, F->Yrow.p, ldr, 1);
+        const unsigned tg = (unsigned)((S.n + 63) / 64);
+        if (cplx)
+            hipLaunchKernelGGL(k_solve_transpose<double2>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
+                               reinterpret_cast<double2 *>(Xcol), dcol, reinterpret_cast<double2 *>(F->Yrow.p), ldr / 2, 1);
+        else
+            hipLaunchKernelGGL(k_solve_transpose<double>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
+                               Xcol, dcol, F->Yrow.p, ldr, 1);
         HIP_TRY(hipGetLastError());
         X = F->Yrow.p;
         d = ldr;
@@ -630,20 +636,23 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
-            if (!cplx && nr >= tuning().solve_mma_min)
-                hipLaunchKernelGGL(k_solve_diag_mma<false>, dim3((unsigned)st.count), dim3(256),
-                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            if (mma && cplx)
+                hipLaunchKernelGGL((k_solve_diag_mma<false, 2>), dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nrr);
+            else if (mma)
+                hipLaunchKernelGGL((k_solve_diag_mma<false, 1>), dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nrr);
             else
                 hipLaunchKernelGGL(cplx ? k_solve_diag_c<false> : k_solve_diag<false>, dim3((unsigned)st.count), dim3(256),
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
             if (st.stiles > 0) {
-                if (!cplx && nr >= tuning().solve_mma_min) {
+                if (mma) {
                     const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
-                    for (int j0 = 0; j0 < nr; j0 += 64)
-                        hipLaunchKernelGGL(k_solve_fwd_mma, dim3(grid), dim3(256), 0, F->stream,
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
                                            P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
-                                           F->Lx.p, F->dLs.p, X, d, nr, j0);
+                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 } else {
                     hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
                                        dim3(cplx ? SOLVE_ROWS : 256), 0, F->stream,
@@ -657,16 +666,16 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;
             if (st.stiles > 0) {
-                if (cplx) {
-                    hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
-                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
-                } else if (nr >= tuning().solve_mma_min) {
+                if (mma) {
                     const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
-                    for (int j0 = 0; j0 < nr; j0 += 64)
-                        hipLaunchKernelGGL(k_solve_bwd_mma, dim3(grid), dim3(256), 0, F->stream,
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma<2> : k_solve_bwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
                                            P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
-                                           F->Lx.p, F->dLs.p, X, d, nr, j0);
+                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                } else if (cplx) {
+                    hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
+                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
                 } else if (nr <= SOLVE_NR) {
                     // a workgroup walks `group` table entries: fewer atomics into the same 64 x nrhs entries of a
                     // tall block, while at least ~128 workgroups stay per launch
@@ -686,9 +695,12 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                        F->Lx.p, F->dLs.p, X, d, nr);
                 }
             }
-            if (!cplx && nr >= tuning().solve_mma_min)
-                hipLaunchKernelGGL(k_solve_diag_mma<true>, dim3((unsigned)st.count), dim3(256),
-                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
+            if (mma && cplx)
+                hipLaunchKernelGGL((k_solve_diag_mma<true, 2>), dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nrr);
+            else if (mma)
+                hipLaunchKernelGGL((k_solve_diag_mma<true, 1>), dim3((unsigned)st.count), dim3(256),
+                                   0, F->stream, P + st.first, F->Dinv.p, X, d, nrr);
             else
                 hipLaunchKernelGGL(cplx ? k_solve_diag_c<true> : k_solve_diag<true>, dim3((unsigned)st.count), dim3(256),
                                    0, F->stream, P + st.first, F->Dinv.p, X, d, nr);
@@ -696,8 +708,13 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         }
     }
     if (mma) {
-        hipLaunchKernelGGL(k_solve_transpose, dim3((unsigned)((S.n + 63) / 64)), dim3(256), 0, F->stream,
-                           S.n, nr, Xcol, dcol, F->Yrow.p, d, 0);
+        const unsigned tg = (unsigned)((S.n + 63) / 64);
+        if (cplx)
+            hipLaunchKernelGGL(k_solve_transpose<double2>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
+                               reinterpret_cast<double2 *>(Xcol), dcol, reinterpret_cast<double2 *>(F->Yrow.p), d / 2, 0);
+        else
+            hipLaunchKernelGGL(k_solve_transpose<double>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
+                               Xcol, dcol, F->Yrow.p, d, 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, F->stream));

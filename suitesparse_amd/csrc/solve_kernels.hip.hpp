@@ -267,23 +267,42 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
 //------------------------------------------------------------------------------
 constexpr int SM_LD = 66;            // LDS row stride in doubles: 16 rows x 4 k land on disjoint banks
 
-// Y (row-major, ld ldr) <- X (column-major, ld ldx) or back; 64 x 64 tiles through LDS, both sides coalesced
-__global__ __launch_bounds__(256) void k_solve_transpose(int64_t n, int nrhs, double *__restrict__ Xc, int64_t ldx,
-                                                         double *__restrict__ Yr, int64_t ldr, int to_rowmajor)
+// Complex L (E = 2): Y is still handled as a REAL row-major matrix -- the interleaved (re, im) pairs of the
+// nrhs complex right-hand sides are 2*nrhs real columns -- and every complex product becomes two real ones:
+//   L x     : columns (re, im) receive  Lr*(xr, xi) + Li*(-xi, xr)
+//   L^H x   : columns (re, im) receive  Lr^T*(xr, xi) + Li^T*(xi, -xr)
+// i.e. the same MFMA loops run twice, once on the real part of L against the image of X as it is, once on
+// the imaginary part against the image with the columns of each pair swapped and one sign flipped.
+
+// the partner column of real column j in its (re, im) pair, with the sign of the second product
+// CONJ = false (L x): (re, im) <- (-xi, +xr);  CONJ = true (L^H x): (re, im) <- (+xi, -xr)
+template <bool CONJ>
+__device__ __forceinline__ double pair_image(const double *__restrict__ rowp, int j)
 {
-    __shared__ double T[64][65];
+    const bool re_slot = (j & 1) == 0;
+    const double v = rowp[j ^ 1];
+    return (re_slot != CONJ) ? -v : v;
+}
+
+// Y (row-major, ld ldr) <- X (column-major, ld ldx) or back; 64 x 64 tiles through LDS, both sides coalesced.
+// T = double (real) or double2 (complex entries move as units).
+template <typename T>
+__global__ __launch_bounds__(256) void k_solve_transpose(int64_t n, int nrhs, T *__restrict__ Xc, int64_t ldx,
+                                                         T *__restrict__ Yr, int64_t ldr, int to_rowmajor)
+{
+    __shared__ T tile[64][65];
     const int tid = threadIdx.x, a = tid & 63, b4 = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     for (int j0 = 0; j0 < nrhs; j0 += 64) {
         __syncthreads();
         for (int b = b4; b < 64; b += 4) {
-            if (to_rowmajor) { if (r0 + a < n && j0 + b < nrhs) T[b][a] = Xc[r0 + a + (int64_t)(j0 + b) * ldx]; }   // T[j][r]
-            else             { if (r0 + b < n && j0 + a < nrhs) T[a][b] = Yr[(r0 + b) * ldr + j0 + a]; }            // T[j][r]
+            if (to_rowmajor) { if (r0 + a < n && j0 + b < nrhs) tile[b][a] = Xc[r0 + a + (int64_t)(j0 + b) * ldx]; }   // tile[j][r]
+            else             { if (r0 + b < n && j0 + a < nrhs) tile[a][b] = Yr[(r0 + b) * ldr + j0 + a]; }            // tile[j][r]
         }
         __syncthreads();
         for (int b = b4; b < 64; b += 4) {
-            if (to_rowmajor) { if (r0 + b < n && j0 + a < nrhs) Yr[(r0 + b) * ldr + j0 + a] = T[a][b]; }
-            else             { if (r0 + a < n && j0 + b < nrhs) Xc[r0 + a + (int64_t)(j0 + b) * ldx] = T[b][a]; }
+            if (to_rowmajor) { if (r0 + b < n && j0 + a < nrhs) Yr[(r0 + b) * ldr + j0 + a] = tile[a][b]; }
+            else             { if (r0 + a < n && j0 + b < nrhs) Xc[r0 + a + (int64_t)(j0 + b) * ldx] = tile[b][a]; }
         }
     }
 }
@@ -291,12 +310,15 @@ __global__ __launch_bounds__(256) void k_solve_transpose(int64_t n, int nrhs, do
 // forward: Y[row(r)][j] -= sum_c L[r][col0+c] * x1[c][j].  Contraction over the 64 columns: L is read straight
 // from global memory in MFMA operand layout (16 consecutive rows per k: 128-byte runs, every entry of the
 // tile read once by exactly one wave); x1 (shared by all tiles of the block) is staged in LDS once per block.
+// ldr, nrhs, j0 count REAL columns of Y (2 per complex right-hand side).
+template <int E>
 __global__ __launch_bounds__(256) void k_solve_fwd_mma(
     const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrhs, int j0)
 {
     __shared__ double Xs[64][SM_LD];                     // Xs[j][c] = x1[c][j0 + j]
+    __shared__ double Xs2[E == 2 ? 64 : 1][SM_LD];       // complex: the pair-swapped image
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int nj = min(64, nrhs - j0);
     const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
@@ -309,24 +331,31 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
             t = tasks[ti];
             __syncthreads();                             // readers of the previous block's x1 are done
             const double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr + j0;
-            for (int idx = tid; idx < 64 * t.nb; idx += 256) {
+            const int nbp = (t.nb + 3) & ~3;             // k padded to whole MFMA steps (zeros)
+            for (int idx = tid; idx < 64 * nbp; idx += 256) {
                 const int j = idx & 63, c = idx >> 6;    // consecutive threads: consecutive right-hand sides
-                Xs[j][c] = (j < nj) ? x1[(int64_t)c * ldr + j] : 0.0;
+                const bool in = c < t.nb && j < nj;
+                Xs[j][c] = in ? x1[(int64_t)c * ldr + j] : 0.0;
+                if constexpr (E == 2) Xs2[j][c] = in ? pair_image<false>(x1 + (int64_t)c * ldr, j) : 0.0;
             }
-            for (int idx = tid; idx < 64 * (((t.nb + 3) & ~3) - t.nb); idx += 256)       // zero the k padding
-                Xs[idx & 63][t.nb + (idx >> 6)] = 0.0;
             __syncthreads();
         }
         const int nb = t.nb;
         const int nq = (nb + 3) >> 2;                    // k-steps of 4 columns that hold anything
         const int rbase = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + w * 16;       // first row of this wave
         const int r = rbase + l15;                       // operand row of this lane
-        const double *__restrict__ Lr = Lx + t.a_off + ((r < t.lda ? r : t.col0) - t.col0);
-        double al[16];
+        const int64_t roff = t.a_off + ((r < t.lda ? r : t.col0) - t.col0);
+        double al[16], ai[E == 2 ? 16 : 1];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = 4 * q + l4;
-            al[q] = (q < nq) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;   // c >= nb: finite value against a zero of Xs
+            const int64_t off = roff + (int64_t)(c < nb ? c : 0) * t.lda;   // c >= nb: finite value against a zero of Xs
+            if constexpr (E == 2) {
+                const double2 v = (q < nq) ? reinterpret_cast<const double2 *>(Lx)[off] : make_double2(0.0, 0.0);
+                al[q] = v.x; ai[q] = v.y;
+            } else {
+                al[q] = (q < nq) ? Lx[off] : 0.0;
+            }
         }
         v4d acc[4];
 #pragma unroll
@@ -338,6 +367,8 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
             for (int jb = 0; jb < 4; jb++) {
                 if (16 * jb >= nj) break;                            // uniform
                 acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], Xs[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
+                if constexpr (E == 2)
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], Xs2[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
             }
         }
         // result: rows rbase + lane/16 + 4g (g = 0..3), right-hand side 16 jb + lane%16
@@ -361,10 +392,12 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
     }
 }
 
-// backward: x1[c][j] -= sum_r L[r][col0+c] * Y[row(r)][j].  Contraction over the rows: the L tile and the
+// backward: x1[c][j] -= sum_r conj(L[r][col0+c]) * Y[row(r)][j].  Contraction over the rows: the L tile and the
 // gathered rows of Y are staged in LDS and read back in operand layout; the products of all the tiles a
 // workgroup walks accumulate in the MFMA registers while the block stays the same, so a tall block sends
-// one set of atomics per workgroup.
+// one set of atomics per workgroup.  Complex: a second pass through the same LDS buffers with Im(L) and the
+// pair-swapped image of Y.
+template <int E>
 __global__ __launch_bounds__(256) void k_solve_bwd_mma(
     const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ tile_task, int64_t ntiles, int group,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
@@ -403,15 +436,23 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
         const int nb = t.nb;
         const int r0 = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS;
         const int rows_here = min(SOLVE_ROWS, t.lda - r0);
+        const int nq = (rows_here + 3) >> 2;             // k-steps of 4 rows that hold anything (the rest is zero)
         const int r = r0 + lane;
         const bool ok = lane < rows_here;
         __syncthreads();                                 // the previous tile's operand reads are done
         if (w == 0) rowof[lane] = !ok ? 0 : (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
-        const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+        const int64_t roff = t.a_off + ((ok ? r : t.col0) - t.col0);
+        double li[E == 2 ? 16 : 1];
 #pragma unroll 4
         for (int q = 0; q < 16; q++) {
             const int c = w * 16 + q;
-            Lt[c][lane] = (ok && c < nb) ? Lr[(int64_t)c * t.lda] : 0.0;
+            if constexpr (E == 2) {
+                const double2 v = (ok && c < nb) ? reinterpret_cast<const double2 *>(Lx)[roff + (int64_t)c * t.lda]
+                                                 : make_double2(0.0, 0.0);
+                Lt[c][lane] = v.x; li[q] = v.y;
+            } else {
+                Lt[c][lane] = (ok && c < nb) ? Lx[roff + (int64_t)c * t.lda] : 0.0;
+            }
         }
         __syncthreads();                                 // rowof visible
         for (int idx = tid; idx < 64 * 64; idx += 256) {
@@ -419,41 +460,64 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
             Xt[j][rr] = (rr < rows_here && j < nj) ? Y[rowof[rr] * ldr + j0 + j] : 0.0;
         }
         __syncthreads();
-        if (16 * w < nb) {                               // wave-uniform; no barrier inside
-            const int nq = (rows_here + 3) >> 2;         // k-steps of 4 rows that hold anything (the rest is zero)
+        auto products = [&]() {
+            if (16 * w < nb) {                           // wave-uniform; no barrier inside
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                if (q >= nq) break;
-                const double al = Lt[16 * w + l15][4 * q + l4];
+                for (int q = 0; q < 16; q++) {
+                    if (q >= nq) break;
+                    const double a = Lt[16 * w + l15][4 * q + l4];
 #pragma unroll
-                for (int jb = 0; jb < 4; jb++) {
-                    if (16 * jb >= nj) break;
-                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al, Xt[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
+                    for (int jb = 0; jb < 4; jb++) {
+                        if (16 * jb >= nj) break;
+                        acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
+                    }
                 }
             }
+        };
+        products();
+        if constexpr (E == 2) {
+            __syncthreads();                             // pass 0 has read Lt and Xt
+#pragma unroll 4
+            for (int q = 0; q < 16; q++) Lt[w * 16 + q][lane] = li[q];
+            for (int idx = tid; idx < 64 * 64; idx += 256) {
+                const int j = idx & 63, rr = idx >> 6;
+                Xt[j][rr] = (rr < rows_here && j < nj) ? pair_image<true>(Y + rowof[rr] * ldr + j0, j) : 0.0;
+            }
+            __syncthreads();
+            products();
         }
     }
     if (cur >= 0) flush();
 }
 
-// x1 <- inv(L11) x1 (TRANS = false) or inv(L11)^T x1 (TRANS = true) for many right-hand sides: a 64 x 64 x nrhs
+// x1 <- inv(L11) x1 (TRANS = false) or inv(L11)^H x1 (TRANS = true) for many right-hand sides: a 64 x 64 x nrhs
 // product per block on the MFMA pipe.  One workgroup per block; wave w owns rows [16w, 16w+16) of the result.
-template <bool TRANS>
+template <bool TRANS, int E>
 __global__ __launch_bounds__(256) void k_solve_diag_mma(
     const PotrfTask *__restrict__ tasks, const double *__restrict__ Dinv,
     double *__restrict__ Y, int64_t ldr, int nrhs)
 {
-    __shared__ double Ds[64][SM_LD];                     // Ds[i][k] = D(i,k), or D(k,i) when TRANS
+    __shared__ double Ds[64][SM_LD];                     // Ds[i][k] = Re D(i,k), or Re D(k,i) when TRANS
     __shared__ double Xs[64][SM_LD];                     // Xs[j][k] = x1[k][j0 + j]
+    __shared__ double Ds2[E == 2 ? 64 : 1][SM_LD];       // complex: Im D the same way
+    __shared__ double Xs2[E == 2 ? 64 : 1][SM_LD];       // complex: pair-swapped image of x1
     const PotrfTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int nb = t.nb;
-    const double *__restrict__ D = Dinv + t.dinv_off;
     double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int i = idx & 63, k = idx >> 6;            // D is column-major, ld nb: consecutive threads read a column
-        const double v = (i < nb && k < nb) ? D[i + k * nb] : 0.0;
-        if (TRANS) Ds[k][i] = v; else Ds[i][k] = v;
+        double vr = 0.0, vi = 0.0;
+        if (i < nb && k < nb) {
+            if constexpr (E == 2) {
+                const double2 v = reinterpret_cast<const double2 *>(Dinv)[t.dinv_off + i + k * nb];
+                vr = v.x; vi = v.y;
+            } else {
+                vr = Dinv[t.dinv_off + i + k * nb];
+            }
+        }
+        if (TRANS) Ds[k][i] = vr; else Ds[i][k] = vr;
+        if constexpr (E == 2) { if (TRANS) Ds2[k][i] = vi; else Ds2[i][k] = vi; }
     }
     const int nq = (nb + 3) >> 2;
     for (int j0 = 0; j0 < nrhs; j0 += 64) {
@@ -461,7 +525,9 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
         __syncthreads();                                 // Ds filled / previous chunk's reads and writes done
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int j = idx & 63, k = idx >> 6;
-            Xs[j][k] = (k < nb && j < nj) ? x1[(int64_t)k * ldr + j0 + j] : 0.0;
+            const bool in = k < nb && j < nj;
+            Xs[j][k] = in ? x1[(int64_t)k * ldr + j0 + j] : 0.0;
+            if constexpr (E == 2) Xs2[j][k] = in ? pair_image<TRANS>(x1 + (int64_t)k * ldr + j0, j) : 0.0;
         }
         __syncthreads();
         if (16 * w < nb) {
@@ -471,11 +537,15 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 if (q >= nq) break;
-                const double al = Ds[16 * w + l15][4 * q + l4];
+                const double a = Ds[16 * w + l15][4 * q + l4];
+                double a2 = 0.0;
+                if constexpr (E == 2) a2 = Ds2[16 * w + l15][4 * q + l4];
 #pragma unroll
                 for (int jb = 0; jb < 4; jb++) {
                     if (16 * jb >= nj) break;
-                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(al, Xs[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xs[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
+                    if constexpr (E == 2)
+                        acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Xs2[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
                 }
             }
 #pragma unroll

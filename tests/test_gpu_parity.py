@@ -246,7 +246,7 @@ def test_zomplex_input_gives_complex_factor(engine):
     assert st == 0 and relerr(L.Lx(), g["Lx"]) < TOL_L
 
 
-@pytest.mark.parametrize("size,nrhs", [(12, 1), (16, 5)])
+@pytest.mark.parametrize("size,nrhs", [(12, 1), (16, 5), (14, 20), (12, 64), (10, 70)])
 def test_complex_hermitian_vs_live_reference(engine, size, nrhs, have_ref):
     """config-5 shaped problem (complex Hermitian shifted Laplacian) incl. multi-RHS solve"""
     if not have_ref:
