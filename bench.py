@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--solve", action="store_true", help="also time the supernodal solve")
     ap.add_argument("--nrhs", type=int, default=1)
-    ap.add_argument("--tune", default="", help="experiments: key=value,... (0 big_min_m, 1 big_min_n, 2 outer block)")
+    ap.add_argument("--tune", default="", help="experiments: key=value,... (keys of mi355_set_tuning, include/mi355_cholmod.h)")
     args = ap.parse_args()
 
     import torch
@@ -199,18 +199,23 @@ def main():
                                  "assembly": round(st["assembly_ms"], 3), "device_total": round(st["total_ms"], 3)}},
         "roofline": roof,
     }
-    if args.solve and world == 1:
+    # the solve is outside the timed region: forward + backward sweep with X resident in HBM.  Default run
+    # (N = 1): nrhs = 1 and 64, the two cases BASELINE.md names; --solve --nrhs K times one case.
+    if world == 1 and (args.solve or not args.no_cpu):
         E = 2 if cplx else 1
-        nrhs = args.nrhs
-        X = torch.ones(p["n"] * nrhs * E, dtype=torch.float64, device="cuda")
-        L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=True)
-        t_f = L.stats()["solve_ms"]
-        L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=False)
-        t_b = L.stats()["solve_ms"]
-        bytes_alg = (2 * sym["xsize"] * 8 + 4 * p["n"] * nrhs * 8) * E
-        out["config"]["solve"] = {"nrhs": nrhs, "forward_ms": round(t_f, 3), "backward_ms": round(t_b, 3),
-                                  "algorithmic_GBs": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9, 1),
-                                  "frac_hbm_peak": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)}
+        sol = []
+        for nrhs in ([args.nrhs] if args.solve else [1, 64]):
+            X = torch.ones(p["n"] * nrhs * E, dtype=torch.float64, device="cuda")
+            L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=True)
+            t_f = L.stats()["solve_ms"]
+            L.solve_dev(X.data_ptr(), nrhs, p["n"], lower=False)
+            t_b = L.stats()["solve_ms"]
+            del X
+            bytes_alg = (2 * sym["xsize"] * 8 + 4 * p["n"] * nrhs * 8) * E
+            sol.append({"nrhs": nrhs, "forward_ms": round(t_f, 3), "backward_ms": round(t_b, 3),
+                        "algorithmic_GBs": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9, 1),
+                        "frac_hbm_peak": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)})
+        out["config"]["solve"] = sol[0] if args.solve else sol
     if rank == 0:
         if world == 1 and not args.no_cpu:
             try:
