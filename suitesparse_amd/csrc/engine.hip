@@ -242,6 +242,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                                    dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
                                    (unsigned long long *)nullptr);
+            else if (st.trsm && !st.big)
+                hipLaunchKernelGGL(k_trsm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p);
             else
                 hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);

@@ -10,6 +10,7 @@
 //                   trailing updates and TRSM-by-inverse inside dpotrf/dtrsm
 //                   (worker :1023,:1175; t_cholmod_gpu.c:784-1135,1151-1393)
 // k_potrf64         dpotrf of one <=64 diagonal block + its inverse            latency
+// k_trsm64          dtrsm of the rows below a panel (worker :1175) by that inverse    latency
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -427,6 +428,67 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
                         C[m + (int64_t)n * ldc] = v;
                     }
                 }
+            }
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_trsm64: X = A * inv(L11)^T for the rows below a 64-column panel (the TRSM of a3.10 in the form of a
+// product with the block inverse kept by k_potrf64), in place.  Every panel step of the factorization waits
+// for this launch, so it is built for latency like k_potrf64: one workgroup per 64-row tile of the
+// tile table (tn = 0), the inverse staged in LDS once, the rows of A read straight from global memory in MFMA
+// operand layout (16 consecutive rows per k: 128-byte runs), no barrier after the staging, and the result
+// stored with the rows along lane%16 (runs of 16 consecutive doubles per column).
+//------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm64(
+    const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
+    const double *__restrict__ Dinv)
+{
+    __shared__ double Ds[NB][NB + 2];                    // Ds[n][k] = inv(L11)(n, k)
+    const Schedule::TileEntry te = tile_tab[blockIdx.x];
+    const GemmTask t = tasks[te.task];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nb = t.N;                                  // = K: order of the diagonal block
+    const int m0 = (int)(te.tmtn & 0xffffu) * TILE;
+    const double *__restrict__ D = Dinv + t.b_off;       // column-major, ld = ldb
+    // rows of A for this wave: 16 rows, operand lane = row, k = column
+    const int r = m0 + 16 * w + l15;
+    const bool ok = r < t.M;
+    double *__restrict__ Ar = Lx + t.a_off + (ok ? r : 0);
+    const int nq = (nb + 3) >> 2, ncb = (nb + 15) >> 4;
+    double b[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int k = 4 * q + l4;
+        b[q] = (q < nq) ? Ar[(int64_t)(k < nb ? k : 0) * t.lda] : 0.0;     // k >= nb meets a zero of Ds
+    }
+    const int np = ncb * 16, kp = nq * 4;
+    for (int idx = tid; idx < np * kp; idx += 256) {
+        const int n = idx % np, k = idx / np;
+        Ds[n][k] = (n < nb && k < nb) ? D[n + (int64_t)k * t.ldb] : 0.0;
+    }
+    __syncthreads();
+    v4d acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) acc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        if (q >= nq) break;                              // uniform
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            if (cb >= ncb) break;
+            acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[16 * cb + l15][4 * q + l4], b[q], acc[cb], 0, 0, 0);
+        }
+    }
+    // result: column 16 cb + lane/16 + 4g, row = lane%16 of this wave's 16 rows
+    if (ok) {
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = 16 * cb + l4 + 4 * g;
+                if (n < nb) Ar[(int64_t)n * t.lda] = acc[cb][g];
             }
         }
     }

@@ -125,13 +125,13 @@ namespace {
 // append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
 // kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
 // tile0 prefix sums
-void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_big)
+void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_big, int32_t trsm = 0)
 {
     if (tasks.empty()) return;
     const Tuning &tu = tuning();
     for (int big = 1; big >= 0; big--) {
         Step st;
-        st.kind = STEP_GEMM; st.level = level; st.big = big; st.pad = 0;
+        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
         st.tmap_off = (int64_t)out.gemm_tile_tab.size();
         std::vector<Schedule::TileEntry> seq;
@@ -352,7 +352,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 ti32++;
             }
             Step st;
-            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.pad = 0;
+            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0;
             st.first = (int64_t)out.potrf.size();
             st.count = (int64_t)ls.potrf[it].size();
             st.ntiles = st.count;
@@ -360,7 +360,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.tmap_off = tmap_off;
             out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
             if (st.count > 0) out.steps.push_back(st);
-            flush_gemm(out, ls.trsm[it], lev, S.no_big);
+            flush_gemm(out, ls.trsm[it], lev, S.no_big, 1);
             flush_gemm(out, ls.trail[it], lev, S.no_big);
         }
         flush_gemm(out, ls.updates, lev, S.no_big);

@@ -73,7 +73,7 @@ struct Step {
     int32_t kind;
     int32_t level;
     int32_t big;        // STEP_GEMM: tasks of this step use the big-tile kernel
-    int32_t pad;
+    int32_t trsm;       // STEP_GEMM: every task is a TRSM by block inverse (GEMM_OVERWRITE, N = K = nb <= 64)
     int64_t first;      // first task (index into potrf[] or gemm[])
     int64_t count;      // number of tasks
     int64_t ntiles;     // STEP_GEMM: total tiles (= grid size); STEP_POTRF: = count
