@@ -57,7 +57,8 @@ template <class T> struct DevBuf {
     }
     hipError_t upload(const T *src, size_t count, hipStream_t st)
     {
-        hipError_t e = alloc(count);
+        hipError_t e = hipSuccess;
+        if (!p || n != count) e = alloc(count);            // same size (refactorization): keep the buffer
         if (e != hipSuccess || count == 0) return e;
         e = hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return e;
