@@ -601,7 +601,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     if (nrhs < 0 || d < S.n) return fail(MI355_INVALID, "X and L dimensions must match");
     if (S.n == 0 || nrhs == 0) return MI355_OK;
     if (!F->numeric_ok) return fail(MI355_INVALID, "no positive-definite numeric factor is resident");
-    if (nrhs > 0x7fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
+    if (nrhs > 0x3fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
     const std::vector<Step> &steps = F->full.sched.steps;
     const PotrfTask *P = F->full.potrf.p;
     hipEvent_t e0, e1;
