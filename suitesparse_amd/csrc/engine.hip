@@ -263,16 +263,18 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             if (st.kind == STEP_POTRF) {
                 fprintf(steplog, "potrf level %d count %lld ms %.4f\n", st.level, (long long)st.count, ms);
             } else {
-                double fl = 0; int kmin = 1 << 30, kmax = 0; int64_t mmax = 0, nmax = 0;
+                double fl = 0, xfl = 0; int kmin = 1 << 30, kmax = 0; int64_t mmax = 0, nmax = 0;
                 for (int64_t i = 0; i < st.count; i++) {
                     const GemmTask &t = D.sched.gemm[(size_t)(st.first + i)];
                     const double Mm = t.M, Nn = t.N, Kk = t.K;
                     fl += (t.mode == GEMM_OVERWRITE) ? 2 * Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
+                    const double tile = st.big ? BTILE : TILE;     // flops the launched tiles execute (full tiles)
+                    xfl += (double)gemm_tiles(t.M, t.N, t.mode, st.big ? BTILE : TILE) * tile * tile * 2.0 * Kk;
                     kmin = std::min(kmin, t.K); kmax = std::max(kmax, t.K);
                     mmax = std::max<int64_t>(mmax, t.M); nmax = std::max<int64_t>(nmax, t.N);
                 }
-                fprintf(steplog, "gemm level %d big %d mode %d count %lld ntiles %lld flops %.6g kmin %d kmax %d mmax %lld nmax %lld ms %.4f\n",
-                        st.level, st.big, D.sched.gemm[(size_t)st.first].mode, (long long)st.count, (long long)st.ntiles, fl,
+                fprintf(steplog, "gemm level %d big %d mode %d count %lld ntiles %lld flops %.6g xflops %.6g kmin %d kmax %d mmax %lld nmax %lld ms %.4f\n",
+                        st.level, st.big, D.sched.gemm[(size_t)st.first].mode, (long long)st.count, (long long)st.ntiles, fl, xfl,
                         kmin, kmax, (long long)mmax, (long long)nmax, ms);
             }
         }
