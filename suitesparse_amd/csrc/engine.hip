@@ -233,16 +233,16 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
         } else {
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
-            const int tk = (st.big && !cplx) ? 3 : 0;
+            const int tk = st.big ? 3 : 0;
             tm.begin(tk);
-            if (cplx)
-                hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
-                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
-            else if (st.big)
-                hipLaunchKernelGGL(k_gemm128, dim3((unsigned)st.ntiles),
+            if (st.big)
+                hipLaunchKernelGGL(cplx ? k_gemm128<true> : k_gemm128<false>, dim3((unsigned)st.ntiles),
                                    dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
                                    (unsigned long long *)nullptr);
+            else if (cplx)
+                hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             else if (st.trsm && !st.big)
                 hipLaunchKernelGGL(k_trsm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p);
@@ -268,8 +268,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                     const GemmTask &t = D.sched.gemm[(size_t)(st.first + i)];
                     const double Mm = t.M, Nn = t.N, Kk = t.K;
                     fl += (t.mode == GEMM_OVERWRITE) ? 2 * Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
-                    const double tile = st.big ? BTILE : TILE;     // flops the launched tiles execute (full tiles)
-                    xfl += (double)gemm_tiles(t.M, t.N, t.mode, st.big ? BTILE : TILE) * tile * tile * 2.0 * Kk;
+                    // flops the launched tiles execute (full tiles; complex counted like fl, once per entry)
+                    xfl += (double)gemm_tiles(t.M, t.N, t.mode, tile_rows(t.big), tile_cols(t.big)) *
+                           tile_rows(t.big) * tile_cols(t.big) * 2.0 * Kk;
                     kmin = std::min(kmin, t.K); kmax = std::max(kmax, t.K);
                     mmax = std::max<int64_t>(mmax, t.M); nmax = std::max<int64_t>(nmax, t.N);
                 }
@@ -344,7 +345,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     const std::string bad = validate_symbolic(F->sym);
     if (!bad.empty()) return fail(MI355_INVALID, "invalid supernodal symbolic factor: " + bad);
 
-    F->sym.no_big = (F->E == 2);        // the complex path has the 64x64-tile kernel only
+    F->sym.cplx = (F->E == 2);          // the big-tile kernel then covers 64 x 128 complex entries per tile
     build_schedule(F->sym, nsuper, 0, F->full.sched);
 
     // device copies of the symbolic arrays (row indices narrowed to int32)
@@ -998,7 +999,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     {
         // same table builder as the factorization (super-tiles, XCD chunks): a one-task step
         std::vector<Schedule::TileEntry> seq;
-        append_tiles(seq, 0, t, kernel ? BTILE : TILE);
+        append_tiles(seq, 0, t, kernel ? BTILE : TILE, kernel ? BTILE : TILE);
         deal_tiles(seq, tab);
         const int64_t n = (int64_t)tab.size();
         if (n != ntiles) return fail(MI355_INVALID, "tile table size mismatch");
@@ -1014,7 +1015,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     for (int it = -2; it < iters; it++) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
         if (kernel >= 1)
-            hipLaunchKernelGGL(k_gemm128, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr,
+            hipLaunchKernelGGL(k_gemm128<false>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr,
                                dstamps.p);
         else
             hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);

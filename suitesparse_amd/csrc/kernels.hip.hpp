@@ -236,6 +236,16 @@ __global__ __launch_bounds__(256) void k_gemm64(
 constexpr int G128_KS = 16;
 constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row => conflict-free ds_read_b64
 
+// CPLX: the same kernel on a complex (interleaved re, im) factor through its REAL view.  A complex column
+// of C, A or B is a real column of twice the length (rows 2m = Re, 2m+1 = Im), so  C = A B^H  becomes the real
+// product  C'' = A'' B''^T  with a doubled contraction:
+//     C''(2m,   n) = sum_k Ar(m,k) Br(n,k) + Ai(m,k) Bi(n,k)
+//     C''(2m+1, n) = sum_k Ai(m,k) Br(n,k) - Ar(m,k) Bi(n,k)
+// i.e. A'' = [ A~ | pair-swapped A~ with a sign ], B'' = [ Re B | Im B ] (rows 2n / 2n+1 of the real view).
+// Only the staging addresses and the index arithmetic of the epilogues change; a tile covers 128 real rows
+// = 64 complex rows by 128 complex columns (the host builds the tile table for that shape, GemmTask::big = 2).
+// The imaginary part of a diagonal entry of C is left alone (it is zero, as zherk keeps it).
+template <bool CPLX>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
     const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap,
@@ -250,24 +260,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     const int64_t bid = blockIdx.x;
     const Schedule::TileEntry te = tile_tab[bid];
     const GemmTask t = tasks[te.task];
-    const int M = t.M, N = t.N, K = t.K, mode = t.mode;
+    constexpr int E = CPLX ? 2 : 1;
+    const int N = t.N, mode = t.mode;
+    const int M = E * t.M;                           // rows of the real view of A and C
+    const int Kc = t.K, K = E * t.K;                 // contraction length: complex entries / real view
     const int tm = (int)(te.tmtn & 0xffffu), tn = (int)(te.tmtn >> 16);
     const int m0 = tm * BTILE, n0 = tn * BTILE;
 
-    const double *__restrict__ A = Lx + t.a_off;
-    const double *__restrict__ B = (mode == GEMM_OVERWRITE ? Dinv : Lx) + t.b_off;
-    const int64_t lda = t.lda, ldb = t.ldb;
+    const double *__restrict__ A = Lx + E * t.a_off;
+    const double *__restrict__ B = (mode == GEMM_OVERWRITE ? Dinv : Lx) + E * t.b_off;
+    const int64_t lda = E * (int64_t)t.lda, ldb = E * (int64_t)t.ldb;
 
     if (mode == GEMM_SCATTER_SUB) {
-        if (tid < BTILE) rmM[tid] = (m0 + tid < M) ? relmap[t.rm_off + m0 + tid] : 0;
-        else { int j = tid - BTILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
+        if (tid < BTILE) {
+            const int m = m0 + tid;
+            rmM[tid] = (m < M) ? (CPLX ? 2 * relmap[t.rm_off + (m >> 1)] + (m & 1) : relmap[t.rm_off + m]) : 0;
+        } else { int j = tid - BTILE; rmN[j] = (n0 + j < N) ? relmap[t.rm_off + n0 + j] : 0; }
     }
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
     // a diagonal tile of a lower-trapezoid task needs nothing from its strictly upper 64x64 quadrant
-    const bool skip_mma = (mode != GEMM_OVERWRITE) && (m0 == n0) && (wm < wn);
+    const bool skip_mma = (mode != GEMM_OVERWRITE) && (((m0 + wm * 64 + 63) >> (E - 1)) < n0 + wn * 64);
 
     // acc[ni][mi][r] is C[m = 16*mi + lane%16][n = 16*ni + 4*r + lane/16] of the wave's 64x64 tile
     v4d acc[4][4];
@@ -278,18 +293,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 
     // each thread stages 8 k-values (lk, lk+2, ..) of one A row and one B row; lk is wave-uniform
     const int lrow = tid & 127, lk = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const double *Ap = A + min(m0 + lrow, M - 1);
-    const double *Bp = B + min(n0 + lrow, N - 1);
+    const int arow = min(m0 + lrow, M - 1), brow = min(n0 + lrow, N - 1);
     double ra[8], rb[8];
+    // element kk (< K) of this thread's row of A'' and of B''; kk is wave-uniform
+    auto load_a = [&](int kk) -> double {
+        if constexpr (!CPLX) {
+            return A[arow + (int64_t)kk * lda];
+        } else {
+            const bool second = kk >= Kc;       // the sign of the pair image is applied on the way into LDS (a_sign)
+            return A[(second ? (arow ^ 1) : arow) + (int64_t)(second ? kk - Kc : kk) * lda];
+        }
+    };
+    // value of A'' from the raw loaded one: the second half of the contraction is -Re in the Im rows
+    auto a_sign = [&](double v, int kk) -> double {
+        if constexpr (CPLX) return (kk >= Kc && (arow & 1)) ? -v : v;
+        else return v;
+    };
+    auto load_b = [&](int kk) -> double {
+        if constexpr (!CPLX) {
+            return B[brow + (int64_t)kk * ldb];
+        } else {
+            const bool second = kk >= Kc;
+            return B[2 * brow + (second ? 1 : 0) + (int64_t)(second ? kk - Kc : kk) * ldb];
+        }
+    };
 
     auto gload1 = [&](int q, int k0) {
         const int kk = min(k0 + lk + 2 * q, K - 1);
-        ra[q] = Ap[(int64_t)kk * lda];
-        rb[q] = Bp[(int64_t)kk * ldb];
+        ra[q] = load_a(kk);
+        rb[q] = load_b(kk);
     };
     auto lstore1 = [&](int q, int k0, int buf) {
-        const bool kok = (k0 + lk + 2 * q) < K;
-        As[buf][lk + 2 * q][lrow] = kok ? ra[q] : 0.0;
+        const int kk = k0 + lk + 2 * q;
+        const bool kok = kk < K;
+        As[buf][lk + 2 * q][lrow] = kok ? a_sign(ra[q], kk) : 0.0;
         Bs[buf][lk + 2 * q][lrow] = kok ? rb[q] : 0.0;
     };
 
@@ -315,15 +352,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     // stage s+1's value goes to the other LDS buffer, then the register is re-loaded for stage s+2
     auto stage_write = [&](int ks, int g, int k0, int buf) {
         const int q = 2 * ks + (g >> 1);
-        const bool kok = (k0 + G128_KS + lk + 2 * q) < K;
-        if ((g & 1) == 0) As[buf ^ 1][lk + 2 * q][lrow] = kok ? ra[q] : 0.0;
+        const int kk = k0 + G128_KS + lk + 2 * q;
+        const bool kok = kk < K;
+        if ((g & 1) == 0) As[buf ^ 1][lk + 2 * q][lrow] = kok ? a_sign(ra[q], kk) : 0.0;
         else Bs[buf ^ 1][lk + 2 * q][lrow] = kok ? rb[q] : 0.0;
     };
     auto stage_load = [&](int ks, int g, int k0) {
         const int q = 2 * ks + (g >> 1);
         const int kk = min(k0 + 2 * G128_KS + lk + 2 * q, K - 1);
-        if ((g & 1) == 0) ra[q] = Ap[(int64_t)kk * lda];
-        else rb[q] = Bp[(int64_t)kk * ldb];
+        if ((g & 1) == 0) ra[q] = load_a(kk);
+        else rb[q] = load_b(kk);
     };
 
     const unsigned long long st1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -382,8 +420,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     mainloop(std::true_type{});
     const unsigned long long st2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    const int64_t ldc = t.ldc;
-    double *__restrict__ C = Lx + t.c_off;
+    const int64_t ldc = E * (int64_t)t.ldc;
+    double *__restrict__ C = Lx + E * t.c_off;
+    // on or below the diagonal (row index of the factor = m >> 1 in the real view of a complex one); the
+    // imaginary part of a diagonal entry is not touched
+    auto lower = [&](int m, int n) {
+        if constexpr (CPLX) return (m >> 1) > n || ((m >> 1) == n && !(m & 1));
+        else return m >= n;
+    };
     if (mode == GEMM_DIRECT_SUB) {
         // read-modify-write in batches of 16: all loads of a batch are issued before the first use, so
         // the wave waits for memory once per batch instead of once per element
@@ -394,13 +438,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
-                const bool ok = (m < M) && (n < N) && (m >= n);
+                const bool ok = (m < M) && (n < N) && lower(m, n);
                 cv[q] = C[ok ? (m + (int64_t)n * ldc) : 0];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
-                if ((m < M) && (n < N) && (m >= n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 2][mi][q & 3];
+                if ((m < M) && (n < N) && lower(m, n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 2][mi][q & 3];
             }
         }
         if (stamps && tid == 0) {
@@ -423,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
                 if (m < M && n < N) {
                     const double v = acc[ni][mi][r];
                     if (mode == GEMM_SCATTER_SUB) {
-                        if (m >= n) atomic_add_f64(C + rmM[ml] + (int64_t)rmN[nl] * ldc, -v);
+                        if (lower(m, n)) atomic_add_f64(C + rmM[ml] + (int64_t)rmN[nl] * ldc, -v);
                     } else {
                         C[m + (int64_t)n * ldc] = v;
                     }

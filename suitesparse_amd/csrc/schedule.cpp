@@ -14,12 +14,22 @@ Tuning &tuning()
 
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile)
 {
+    return gemm_tiles(M, N, mode, tile, tile);
+}
+
+// tiles of a task that hold at least one entry to compute: all of them (GEMM_OVERWRITE), or those of the
+// lower trapezoid (some row index >= some column index inside the tile)
+int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile_m, int32_t tile_n)
+{
     if (M <= 0 || N <= 0) return 0;
-    int64_t MT = (M + tile - 1) / tile, NT = (N + tile - 1) / tile;
-    if (mode == GEMM_OVERWRITE) return MT * NT;
-    // lower trapezoid (M >= N): tile row tm holds min(tm+1, NT) tiles
-    if (MT < NT) return MT * NT;    // never for our tasks; kept safe
-    return NT * (NT + 1) / 2 + (MT - NT) * NT;
+    const int64_t MT = (M + tile_m - 1) / tile_m, NT = (N + tile_n - 1) / tile_n;
+    if (mode == GEMM_OVERWRITE || M < N) return MT * NT;      // lower-trapezoid tasks have M >= N
+    int64_t count = 0;
+    for (int64_t tm = 0; tm < MT; tm++) {
+        const int64_t last_row = std::min<int64_t>(tm * tile_m + tile_m, M) - 1;
+        count += std::min<int64_t>(NT, last_row / tile_n + 1);
+    }
+    return count;
 }
 
 std::string validate_symbolic(const Symbolic &S)
@@ -85,21 +95,28 @@ GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int
 
 // tiles of one task in super-tile order: G x G groups of tiles (G = tuning().supertile; 1 = plain
 // row-major over the lower trapezoid), row-major over the groups
-void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile)
+void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n)
 {
     const int64_t G = std::max(1, tuning().supertile);
-    const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
-    const bool lower = (t.mode != GEMM_OVERWRITE) && (MT >= NT);
+    const int64_t MT = (t.M + tile_m - 1) / tile_m, NT = (t.N + tile_n - 1) / tile_n;
+    const bool lower = (t.mode != GEMM_OVERWRITE) && t.M >= t.N;
+    // columns of tile row tm that hold an entry on or below the diagonal
+    auto ncols = [&](int64_t tm) {
+        if (!lower) return NT;
+        const int64_t last_row = std::min<int64_t>(tm * tile_m + tile_m, t.M) - 1;
+        return std::min<int64_t>(NT, last_row / tile_n + 1);
+    };
     for (int64_t I = 0; I < MT; I += G)
-        for (int64_t J = 0; J < NT && (!lower || J <= I + G - 1); J += G)
-            for (int64_t tm = I; tm < std::min(I + G, MT); tm++)
-                for (int64_t tn = J; tn < std::min(J + G, NT); tn++) {
-                    if (lower && tn > tm) continue;
+        for (int64_t J = 0; J < NT; J += G)
+            for (int64_t tm = I; tm < std::min(I + G, MT); tm++) {
+                const int64_t nc = ncols(tm);
+                for (int64_t tn = J; tn < std::min(J + G, nc); tn++) {
                     Schedule::TileEntry e;
                     e.task = task;
                     e.tmtn = (uint32_t)tm | ((uint32_t)tn << 16);
                     seq.push_back(e);
                 }
+            }
 }
 
 // workgroup b runs entry u(b) of the sequence.  With tuning().xcd_deal the sequence is dealt to the
@@ -125,7 +142,7 @@ namespace {
 // append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
 // kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
 // tile0 prefix sums
-void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_big, int32_t trsm = 0)
+void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, const Symbolic &S, int32_t trsm = 0)
 {
     if (tasks.empty()) return;
     const Tuning &tu = tuning();
@@ -136,15 +153,17 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, bool no_
         st.tmap_off = (int64_t)out.gemm_tile_tab.size();
         std::vector<Schedule::TileEntry> seq;
         for (auto &t : tasks) {
-            const int is_big = (!no_big && t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
+            // a complex factor's big tile is 64 x 128 entries: the row threshold counts real rows
+            const int is_big = (!S.no_big && (S.cplx ? 2 : 1) * t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
             if (is_big != big) continue;
-            int64_t nt = gemm_tiles(t.M, t.N, t.mode, big ? BTILE : TILE);
+            const int tbig = big ? (S.cplx ? 2 : 1) : 0;
+            int64_t nt = gemm_tiles(t.M, t.N, t.mode, tile_rows(tbig), tile_cols(tbig));
             if (nt == 0) continue;
-            t.big = big;
+            t.big = tbig;
             t.tile0 = st.ntiles;
             st.ntiles += nt;
             out.gemm.push_back(t);
-            append_tiles(seq, (int32_t)st.count, t, big ? BTILE : TILE);
+            append_tiles(seq, (int32_t)st.count, t, tile_rows(tbig), tile_cols(tbig));
             {
                 const double Mm = t.M, Nn = t.N, Kk = t.K;
                 const double fl = (t.mode == GEMM_OVERWRITE) ? Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
@@ -167,8 +186,8 @@ bool check_tile_table(const Schedule &sc, const Step &st)
     std::vector<std::vector<uint8_t>> seen((size_t)st.count);
     for (int64_t i = 0; i < st.count; i++) {
         const GemmTask &t = sc.gemm[(size_t)(st.first + i)];
-        const int tile = t.big ? BTILE : TILE;
-        const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
+        const int tr = tile_rows(t.big), tc = tile_cols(t.big);
+        const int64_t MT = (t.M + tr - 1) / tr, NT = (t.N + tc - 1) / tc;
         seen[(size_t)i].assign((size_t)(MT * NT), 0);
     }
     int64_t count = 0;
@@ -176,11 +195,12 @@ bool check_tile_table(const Schedule &sc, const Step &st)
         const Schedule::TileEntry e = sc.gemm_tile_tab[(size_t)(st.tmap_off + b)];
         if (e.task < 0 || e.task >= st.count) return false;
         const GemmTask &t = sc.gemm[(size_t)(st.first + e.task)];
-        const int tile = t.big ? BTILE : TILE;
-        const int64_t MT = (t.M + tile - 1) / tile, NT = (t.N + tile - 1) / tile;
+        const int tr = tile_rows(t.big), tc = tile_cols(t.big);
+        const int64_t MT = (t.M + tr - 1) / tr, NT = (t.N + tc - 1) / tc;
         const int64_t tm = e.tmtn & 0xffff, tn = e.tmtn >> 16;
         if (tm >= MT || tn >= NT) return false;
-        if (t.mode != GEMM_OVERWRITE && MT >= NT && tn > tm) return false;
+        // a tile of a lower-trapezoid task must hold an entry on or below the diagonal
+        if (t.mode != GEMM_OVERWRITE && t.M >= t.N && std::min<int64_t>(tm * tr + tr, t.M) - 1 < tn * tc) return false;
         uint8_t &f = seen[(size_t)e.task][(size_t)(tm * NT + tn)];
         if (f) return false;
         f = 1;
@@ -189,7 +209,7 @@ bool check_tile_table(const Schedule &sc, const Step &st)
     int64_t want = 0;
     for (int64_t i = 0; i < st.count; i++) {
         const GemmTask &t = sc.gemm[(size_t)(st.first + i)];
-        want += gemm_tiles(t.M, t.N, t.mode, t.big ? BTILE : TILE);
+        want += gemm_tiles(t.M, t.N, t.mode, tile_rows(t.big), tile_cols(t.big));
     }
     return count == want && want == st.ntiles;
 }
@@ -360,10 +380,10 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.tmap_off = tmap_off;
             out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
             if (st.count > 0) out.steps.push_back(st);
-            flush_gemm(out, ls.trsm[it], lev, S.no_big, 1);
-            flush_gemm(out, ls.trail[it], lev, S.no_big);
+            flush_gemm(out, ls.trsm[it], lev, S, 1);
+            flush_gemm(out, ls.trail[it], lev, S);
         }
-        flush_gemm(out, ls.updates, lev, S.no_big);
+        flush_gemm(out, ls.updates, lev, S);
     }
 }
 

@@ -84,7 +84,8 @@ struct Step {
 struct Symbolic {
     int64_t n = 0, nsuper = 0, ssize = 0, xsize = 0;
     const int64_t *Super = nullptr, *Lpi = nullptr, *Lpx = nullptr, *Ls = nullptr;
-    bool no_big = false;        // route every GEMM task to the 64x64-tile kernel (complex factors)
+    bool no_big = false;        // route every GEMM task to the 64x64-tile kernel
+    bool cplx = false;          // complex factor: the big-tile kernel covers 64 x 128 complex entries per tile
 };
 
 struct Schedule {
@@ -134,7 +135,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
 struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; };
 Tuning &tuning();
-void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile);
+void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);
 
 // true if the table of step st lists every valid tile of every task of the step exactly once
@@ -142,5 +143,10 @@ bool check_tile_table(const Schedule &sc, const Step &st);
 
 // number of TILE-tiles of one task
 int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile);
+int64_t gemm_tiles(int32_t M, int32_t N, int32_t mode, int32_t tile_m, int32_t tile_n);
+// tile shape (rows, columns, in entries of the factor) by GemmTask::big: 0 = k_gemm64(c) 64 x 64,
+// 1 = k_gemm128 128 x 128, 2 = k_gemm128 on a complex factor: 64 x 128 complex entries (128 x 128 reals)
+inline int tile_rows(int big) { return big == 1 ? BTILE : TILE; }
+inline int tile_cols(int big) { return big == 0 ? TILE : BTILE; }
 
 }  // namespace mi355

@@ -77,7 +77,7 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const GemmTask &t = sc.gemm[ti];
                 if (t.tile0 != tiles) { info[S.nsuper + 1] = -1; }       // prefix sums must be exact
-                tiles += gemm_tiles(t.M, t.N, t.mode, t.big ? BTILE : TILE);
+                tiles += gemm_tiles(t.M, t.N, t.mode, tile_rows(t.big), tile_cols(t.big));
                 if (t.big != st.big) info[S.nsuper + 1] = -1;
                 const double *A = Lx + t.a_off;
                 const double *B = (t.mode == GEMM_OVERWRITE ? Dinv.data() : Lx) + t.b_off;
@@ -116,6 +116,30 @@ void emu_set_tuning(int key, int value)
     else if (key == 5) tuning().xcd_deal = value;
     else if (key == 7) tuning().ob2 = value;
     else if (key == 8) tuning().ob3 = value;
+}
+
+// tile tables of the schedule built for a complex factor (rectangular big tiles): 0 if every GEMM step's table
+// lists exactly the tiles that hold an entry on or below the diagonal, once each; else the number of bad steps
+int emu_check_tile_tables(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                          const int64_t *Ls, int64_t ssize, int64_t xsize, int cplx, int64_t *nbig_tiles)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls; S.cplx = cplx != 0;
+    if (!validate_symbolic(S).empty()) return -4;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    int bad = 0;
+    int64_t nb = 0;
+    for (const Step &st : sc.steps) {
+        if (st.kind != STEP_GEMM) continue;
+        if (!check_tile_table(sc, st)) bad++;
+        if (st.big) nb += st.ntiles;
+        for (int64_t i = 0; i < st.count; i++) {
+            const GemmTask &t = sc.gemm[(size_t)(st.first + i)];
+            if (t.big != (st.big ? (cplx ? 2 : 1) : 0)) bad++;
+        }
+    }
+    if (nbig_tiles) *nbig_tiles = nb;
+    return bad;
 }
 
 // returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them

@@ -54,6 +54,21 @@ def backward_error_S(g, X):
 REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
 
 
+@pytest.mark.parametrize("cplx", [0, 1])
+@pytest.mark.parametrize("n", [100, 200, 321, 700])
+def test_tile_tables_rectangular_tiles(emu, n, cplx):
+    """tile tables of dense supernodes wide enough for the big-tile kernel, for a real factor (128 x 128 tiles)
+    and a complex one (64 x 128 entries per tile): every tile on or below the diagonal exactly once."""
+    emu.emu_check_tile_tables.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
+                                          C.c_int, i64p]
+    nb = np.zeros(1, dtype=np.int64)
+    bad = emu.emu_check_tile_tables(n, 1, np.array([0, n], dtype=np.int64), np.array([0, n], dtype=np.int64),
+                                    np.array([0, n * n], dtype=np.int64), np.arange(n, dtype=np.int64), n, n * n,
+                                    cplx, nb)
+    assert bad == 0
+    assert (nb[0] > 0) == (n >= 192 // (2 if cplx else 1) + 64)      # wide enough for a big trailing update
+
+
 @pytest.mark.parametrize("n,ob,ob2", [(700, 128, 0), (700, 128, 256), (1000, 192, 576), (333, 64, 128), (1300, 512, 1024),
                                       (900, 128, 512), (130, 512, 2048)])
 def test_dense_supernode_blocking(emu, n, ob, ob2):
