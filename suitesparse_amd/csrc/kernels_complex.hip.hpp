@@ -162,83 +162,185 @@ __global__ __launch_bounds__(256) void k_gemm64c(
 }
 
 //------------------------------------------------------------------------------
-// k_potrf64c: zpotrf of one nb x nb (nb <= 64) diagonal block + its inverse, all in LDS
+// k_potrf64c: zpotrf of one nb x nb (nb <= 64) diagonal block + its inverse.  Same construction as
+// k_potrf64 (kernels.hip.hpp): right-looking over 16-column blocks; the 16 x 16 diagonal block and its
+// inverse in the registers of one wave (lane = row, values move between lanes with v_readlane), the block
+// TRSM, trailing update and the assembly of the 64 x 64 inverse as 16x16x4 FP64 MFMA products -- four real
+// products per complex one, on de-interleaved LDS images.  The imaginary part of a pivot is ignored and
+// stored as zero (zpotrf).
 //------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_potrf64c(
     const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
     double *__restrict__ Dinv, int *__restrict__ info)
 {
-    __shared__ double Lr[NB][NB + 1], Li[NB][NB + 1];
-    __shared__ double Xr[NB][NB + 1], Xi[NB][NB + 1];
+    __shared__ double Lr[NB][NB + 1], Li[NB][NB + 1];         // the block, factorized in place
+    __shared__ double Vr[NB][NB + 1], Vi[NB][NB + 1];         // its inverse
     const PotrfTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const int nb = t.nb;
     const int64_t lda = t.lda;
     v2d *__restrict__ A = (v2d *)Lx + t.a_off;
 
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx & (NB - 1), j = idx >> 6;
-        double vr = (i == j) ? 1.0 : 0.0, vi = 0.0;             // identity padding
+    const int nblk = (nb + 15) >> 4;                          // 16-column blocks that hold anything
+    const int np = nblk * 16;                                 // padded order: identity beyond nb
+    for (int idx = tid; idx < np * np; idx += 256) {
+        const int i = idx % np, j = idx / np;
+        double vr = (i == j) ? 1.0 : 0.0, vi = 0.0;           // identity padding
         if (i < nb && j < nb) {
             if (i >= j) { const v2d v = A[i + (int64_t)j * lda]; vr = v.x; vi = (i == j) ? 0.0 : v.y; }
             else vr = 0.0;
         }
         Lr[i][j] = vr; Li[i][j] = vi;
-        Xr[i][j] = (i == j) ? 1.0 : 0.0; Xi[i][j] = 0.0;
+        Vr[i][j] = 0.0; Vi[i][j] = 0.0;
     }
     __syncthreads();
 
-    bool failed = false;
-    for (int j = 0; j < nb; j++) {
-        const double d = Lr[j][j];
-        if (!(d > 0.0) && !failed) {
-            failed = true;
-            if (tid == 0 && info[t.s] == 0) info[t.s] = t.col0 + j + 1;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // P += X * Y^H on 16 x 16 blocks (rows of X and Y along the first index, contraction along the second):
+    // Pr += Xr Yr^T + Xi Yi^T, Pi += Xi Yr^T - Xr Yi^T; result element [row = lane/16 + 4g][col = lane%16]
+    auto mma_xyh = [&](const double (*Xr_)[NB + 1], const double (*Xi_)[NB + 1], int xr0, int xc0,
+                       const double (*Yr_)[NB + 1], const double (*Yi_)[NB + 1], int yr0, int yc0, v4d &pr, v4d &pi) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double xr = Xr_[xr0 + l15][xc0 + 4 * q + l4], xi = Xi_[xr0 + l15][xc0 + 4 * q + l4];
+            const double yr = Yr_[yr0 + l15][yc0 + 4 * q + l4], yi = Yi_[yr0 + l15][yc0 + 4 * q + l4];
+            pr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, yr, pr, 0, 0, 0);
+            pr = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, yi, pr, 0, 0, 0);
+            pi = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, yr, pi, 0, 0, 0);
+            pi = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, yi, pi, 0, 0, 0);
         }
-        const double ljj = sqrt(d);
+    };
+    int fail_col = 0;                                         // wave 0 only: 1-based column of the first bad pivot
+#pragma unroll 1
+    for (int jb = 0; jb < nblk; jb++) {
+        const int c0 = 16 * jb;
+        if (wave == 0) {
+            // lane r (mod 16) holds row r of the diagonal block; entries right of the diagonal are never
+            // consumed (they collect harmless junk) and are written back as zeros
+            double ar[16], ai[16], rs[16], wr[16], wi[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { ar[k] = Lr[c0 + l15][c0 + k]; ai[k] = Li[c0 + l15][c0 + k]; }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const double d = lane_bcast(ar[j], j);        // pivot: real part only
+                fail_col = (!(d > 0.0) && fail_col == 0) ? c0 + j + 1 : fail_col;
+                const double r = rsqrt(d);
+                rs[j] = r;
+                ar[j] = (l15 == j) ? d * r : ar[j] * r;
+                ai[j] = (l15 == j) ? 0.0 : ai[j] * r;
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) {             // a(i,k) -= l(i,j) * conj(l(k,j))
+                    const double br = lane_bcast(ar[j], k), bi = lane_bcast(ai[j], k);
+                    ar[k] -= ar[j] * br + ai[j] * bi;
+                    ai[k] -= ai[j] * br - ar[j] * bi;
+                }
+                __builtin_amdgcn_sched_barrier(0);            // keeps the broadcast values (SGPRs) short-lived
+            }
+            // W = inv(L_jj): lane c holds column c, w[i] = (delta_ic - sum_{k<i} L[i][k] w[k]) / L[i][i]
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double accr = (l15 == i) ? 1.0 : 0.0, acci = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) {
+                    const double lr = lane_bcast(ar[k], i), li = lane_bcast(ai[k], i);
+                    accr -= lr * wr[k] - li * wi[k];
+                    acci -= lr * wi[k] + li * wr[k];
+                }
+                wr[i] = accr * rs[i];
+                wi[i] = acci * rs[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    Lr[c0 + lane][c0 + k] = (k <= lane) ? ar[k] : 0.0;
+                    Li[c0 + lane][c0 + k] = (k <= lane) ? ai[k] : 0.0;
+                    Vr[c0 + k][c0 + lane] = wr[k];
+                    Vi[c0 + k][c0 + lane] = wi[k];
+                }
+            }
+        }
         __syncthreads();
-        if (tid == 0) { Lr[j][j] = ljj; Li[j][j] = 0.0; }
-        for (int i = j + 1 + tid; i < nb; i += 256) { Lr[i][j] /= ljj; Li[i][j] /= ljj; }
+        // TRSM: X_ib = A(ib,jb) * W^H for the block rows below (one per wave)
+        {
+            const int ib = jb + 1 + wave;
+            if (ib < nblk) {
+                v4d xr = {0.0, 0.0, 0.0, 0.0}, xi = {0.0, 0.0, 0.0, 0.0};
+                mma_xyh(Lr, Li, 16 * ib, c0, Vr, Vi, c0, c0, xr, xi);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    Lr[16 * ib + l4 + 4 * g][c0 + l15] = xr[g];
+                    Li[16 * ib + l4 + 4 * g][c0 + l15] = xi[g];
+                }
+            }
+        }
         __syncthreads();
-        const int i = j + 1 + (tid & 63);
-        if (i < nb) {
-            const double ar = Lr[i][j], ai = Li[i][j];
-            for (int k = j + 1 + (tid >> 6); k <= i; k += 4) {
-                const double br = Lr[k][j], bi = Li[k][j];          // L(i,k) -= L(i,j) * conj(L(k,j))
-                Lr[i][k] -= ar * br + ai * bi;
-                Li[i][k] -= ai * br - ar * bi;
+        // trailing update: A(ib,kb) -= X_ib X_kb^H for jb < kb <= ib < nblk, block pairs dealt to the waves
+        {
+            const int nrem = nblk - 1 - jb, npairs = nrem * (nrem + 1) / 2;
+            for (int p = wave; p < npairs; p += 4) {
+                int ib = 0, q = p;
+                while (q > ib) { q -= ib + 1; ib++; }          // p -> (ib, q): q <= ib
+                const int bi_ = jb + 1 + ib, bk = jb + 1 + q;
+                v4d cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+                mma_xyh(Lr, Li, 16 * bi_, c0, Lr, Li, 16 * bk, c0, cr, ci);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    Lr[16 * bi_ + l4 + 4 * g][16 * bk + l15] -= cr[g];
+                    Li[16 * bi_ + l4 + 4 * g][16 * bk + l15] -= ci[g];
+                }
             }
         }
         __syncthreads();
     }
 
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx & (NB - 1), j = idx >> 6;
-        if (i < nb && j < nb && i >= j) { v2d v = {Lr[i][j], (i == j) ? 0.0 : Li[i][j]}; A[i + (int64_t)j * lda] = v; }
+    if (tid == 0 && fail_col != 0 && info[t.s] == 0) info[t.s] = t.col0 + fail_col;
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int i = idx % nb, j = idx / nb;
+        if (i >= j) { v2d v = {Lr[i][j], (i == j) ? 0.0 : Li[i][j]}; A[i + (int64_t)j * lda] = v; }
     }
 
-    // X = inv(L): column sweep in LDS; thread (c, part) owns rows i = part (mod 4) of column c
-    {
-        const int c = tid & 63, part = tid >> 6;
-        for (int k = 0; k < NB; k++) {
-            const double dk = Lr[k][k];                               // real, > 0 (1 in the padding)
-            const double xr = Xr[k][c] / dk, xi = Xi[k][c] / dk;
-            __syncthreads();
-            if (part == 0) { Xr[k][c] = xr; Xi[k][c] = xi; }
-            for (int i = k + 1 + ((part - (k + 1)) & 3); i < NB; i += 4) {
-                const double lr = Lr[i][k], li = Li[i][k];
-                Xr[i][c] -= lr * xr - li * xi;
-                Xi[i][c] -= lr * xi + li * xr;
+    // off-diagonal blocks of the inverse, by distance d from the diagonal:
+    // V(i,j) = -W_i * sum_{k=j}^{i-1} L(i,k) V(k,j) (plain complex products); the sum's MFMA result registers
+    // are the B operand of W_i * (.)
+    for (int d = 1; d < nblk; d++) {
+        const int j = wave, i = wave + d;
+        if (i < nblk) {
+            v4d tr = {0.0, 0.0, 0.0, 0.0}, ti = {0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; k++) {
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    const double lr = Lr[16 * i + l15][16 * k + 4 * z + l4], li = Li[16 * i + l15][16 * k + 4 * z + l4];
+                    const double vr = Vr[16 * k + 4 * z + l4][16 * j + l15], vi = Vi[16 * k + 4 * z + l4][16 * j + l15];
+                    tr = __builtin_amdgcn_mfma_f64_16x16x4f64(lr, vr, tr, 0, 0, 0);
+                    tr = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, vi, tr, 0, 0, 0);
+                    ti = __builtin_amdgcn_mfma_f64_16x16x4f64(lr, vi, ti, 0, 0, 0);
+                    ti = __builtin_amdgcn_mfma_f64_16x16x4f64(li, vr, ti, 0, 0, 0);
+                }
             }
-            __syncthreads();
+            v4d vr = {0.0, 0.0, 0.0, 0.0}, vi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                const double wr = Vr[16 * i + l15][16 * i + 4 * z + l4], wi = Vi[16 * i + l15][16 * i + 4 * z + l4];
+                vr = __builtin_amdgcn_mfma_f64_16x16x4f64(wr, tr[z], vr, 0, 0, 0);
+                vr = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, ti[z], vr, 0, 0, 0);
+                vi = __builtin_amdgcn_mfma_f64_16x16x4f64(wr, ti[z], vi, 0, 0, 0);
+                vi = __builtin_amdgcn_mfma_f64_16x16x4f64(wi, tr[z], vi, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                Vr[16 * i + l4 + 4 * g][16 * j + l15] = -vr[g];
+                Vi[16 * i + l4 + 4 * g][16 * j + l15] = -vi[g];
+            }
         }
+        __syncthreads();
     }
     if (t.dinv_off >= 0) {
         v2d *__restrict__ D = (v2d *)Dinv + t.dinv_off;
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx % nb, j = idx / nb;
             v2d v = {0.0, 0.0};
-            if (i >= j) { v.x = Xr[i][j]; v.y = Xi[i][j]; }
+            if (i >= j) { v.x = Vr[i][j]; v.y = Vi[i][j]; }
             D[idx] = v;
         }
     }
