@@ -223,6 +223,30 @@ def main():
                         "algorithmic_GBs": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9, 1),
                         "frac_hbm_peak": round(bytes_alg / ((t_f + t_b) * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)})
         out["config"]["solve"] = sol[0] if args.solve else sol
+    elif world > 1 and not args.no_cpu:
+        # N > 1: sweeps over the own subtrees + ONE all-reduce of X per sweep + replicated top sweeps
+        # (multigpu.PartitionedFactor.lsolve / ltsolve); wall clock, barrier on both sides, max over the ranks
+        E = 2 if cplx else 1
+        sol = []
+        for nrhs in ([args.nrhs] if args.solve else [1, 64]):
+            X = torch.ones(p["n"] * nrhs * E, dtype=torch.float64, device="cuda")
+            runner.lsolve(X, nrhs)          # untimed: workspaces, communicator warm-up
+            runner.ltsolve(X, nrhs)
+            X.fill_(1.0)
+            sync()
+            t0 = time.time()
+            runner.lsolve(X, nrhs)
+            sync()
+            t1 = time.time()
+            runner.ltsolve(X, nrhs)
+            sync()
+            t2 = time.time()
+            tt = torch.tensor([t1 - t0, t2 - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            del X
+            sol.append({"nrhs": nrhs, "forward_ms": round(float(tt[0]) * 1e3, 3),
+                        "backward_ms": round(float(tt[1]) * 1e3, 3)})
+        out["config"]["solve"] = sol[0] if args.solve else sol
     if rank == 0:
         if world == 1 and not args.no_cpu:
             try:

@@ -115,6 +115,17 @@ int mi355_factor_set_partition(mi355_factor *handle, const int8_t *local_mask,
 int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,
                                int64_t *first_bad, int64_t *info);
 
+/* Solves on a partitioned factor (after both phases succeeded on every rank; no counterpart in the
+ * reference).  X is a device pointer, n x nrhs entries, leading dimension d, as in mi355_super_lsolve_dev.
+ *   mi355_super_solve_phase_dev: the forward (lower != 0) or backward sweep over the supernodes of one
+ *     part only -- 0: this rank's subtrees, 1: the top (replicated on every rank).
+ *   mi355_solve_keep_rows_dev: zeroes the rows of X that belong to supernodes outside asm_mask, so that a
+ *     sum over the ranks (RCCL all-reduce of X) is the union of the ranks' rows.
+ * L x = b on N ranks: keep_rows; phase(0, lower); all-reduce X; phase(1, lower).
+ * L' x = b: phase(1, upper); phase(0, upper); keep_rows; all-reduce X.   (suitesparse_amd/multigpu.py) */
+int mi355_super_solve_phase_dev(mi355_factor *handle, int part, int lower, int64_t nrhs, double *X, int64_t d);
+int mi355_solve_keep_rows_dev(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);
+
 /* ---- supernodal triangular solves: replace cholmod_l_super_lsolve / _ltsolve
  *      (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153; workers
  *      t_cholmod_super_solve_worker.c:20-303,309-580).  X is n x nrhs, column-major,

@@ -105,6 +105,7 @@ struct mi355_factor_s {
     DevBuf<double> Ax;
     bool have_A = false, A_unpacked = false;
     bool numeric_ok = false;    // a positive-definite factor is resident
+    bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
     int64_t minor = 0;
     // instrumentation
     int profile = 0;
@@ -541,7 +542,9 @@ int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const 
     F->part_local = new DeviceSchedule;
     F->part_top = new DeviceSchedule;
     build_schedule(S, S.nsuper, 0, F->part_local->sched, local_mask);
-    build_schedule(S, S.nsuper, 0, F->part_top->sched, top_mask);
+    // the top's block inverses sit behind the own subtrees' in Dinv: the solve phases need both
+    build_schedule(S, S.nsuper, 0, F->part_top->sched, top_mask, F->part_local->sched.dinv_size);
+    F->part_ok = false;
     rc = upload_schedule(F, *F->part_local);
     if (rc) return rc;
     rc = upload_schedule(F, *F->part_top);
@@ -560,6 +563,7 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     if (phase != 0 && phase != 1) return fail(MI355_INVALID, "phase must be 0 (own subtrees) or 1 (top)");
     const Symbolic &S = F->sym;
     F->numeric_ok = false;
+    F->part_ok = false;
     if (first_bad) *first_bad = -1;
     if (info_out) *info_out = 0;
     if (S.nsuper == 0) return MI355_OK;
@@ -594,19 +598,24 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
         HIP_TRY(hipMemcpy(&info, F->info.p + sf, sizeof(int), hipMemcpyDeviceToHost));
         if (first_bad) *first_bad = sf;
         if (info_out) *info_out = info;
+    } else if (phase == 1) {
+        F->part_ok = true;      // the caller vouches for phase 0 (on every rank) having succeeded
     }
     return MI355_OK;
 }
 
-static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d)
+// part == nullptr: the whole factor; else the sweeps over one masked schedule of a partitioned factor
+static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr)
 {
     const Symbolic &S = F->sym;
     if (nrhs < 0 || d < S.n) return fail(MI355_INVALID, "X and L dimensions must match");
     if (S.n == 0 || nrhs == 0) return MI355_OK;
-    if (!F->numeric_ok) return fail(MI355_INVALID, "no positive-definite numeric factor is resident");
+    if (!(part ? F->part_ok : F->numeric_ok))
+        return fail(MI355_INVALID, "no positive-definite numeric factor is resident");
     if (nrhs > 0x3fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
-    const std::vector<Step> &steps = F->full.sched.steps;
-    const PotrfTask *P = F->full.potrf.p;
+    DeviceSchedule &DS = part ? *part : F->full;
+    const std::vector<Step> &steps = DS.sched.steps;
+    const PotrfTask *P = DS.potrf.p;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -658,12 +667,12 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
                     for (int j0 = 0; j0 < nrr; j0 += 64)
                         hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           P + st.first, DS.solve_tmap.p + st.tmap_off, st.stiles, group,
                                            F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 } else {
                     hipLaunchKernelGGL(cplx ? k_solve_fwd_update_c : k_solve_fwd_update, dim3((unsigned)st.stiles),
                                        dim3(cplx ? SOLVE_ROWS : 256), 0, F->stream,
-                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+                                       P + st.first, DS.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
                 }
             }
             HIP_TRY(hipGetLastError());
@@ -678,11 +687,11 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
                     for (int j0 = 0; j0 < nrr; j0 += 64)
                         hipLaunchKernelGGL(cplx ? k_solve_bwd_mma<2> : k_solve_bwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           P + st.first, DS.solve_tmap.p + st.tmap_off, st.stiles, group,
                                            F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 } else if (cplx) {
                     hipLaunchKernelGGL(k_solve_bwd_update_c, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
-                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+                                       P + st.first, DS.solve_tmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
                 } else if (nr <= SOLVE_NR) {
                     // a workgroup walks `group` table entries: fewer atomics into the same 64 x nrhs entries of a
                     // tall block, while at least ~128 workgroups stay per launch
@@ -690,15 +699,15 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                     const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
                     if (nr == 1)
                         hipLaunchKernelGGL(k_solve_bwd_update<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           P + st.first, DS.solve_tmap.p + st.tmap_off, st.stiles, group,
                                            F->Lx.p, F->dLs.p, X, d, nr);
                     else
                         hipLaunchKernelGGL(k_solve_bwd_update<SOLVE_NR>, dim3(grid), dim3(256), 0, F->stream,
-                                           P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, group,
+                                           P + st.first, DS.solve_tmap.p + st.tmap_off, st.stiles, group,
                                            F->Lx.p, F->dLs.p, X, d, nr);
                 } else {
                     hipLaunchKernelGGL(k_solve_bwd_update<0>, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
-                                       P + st.first, F->full.solve_tmap.p + st.tmap_off, st.stiles, 1,
+                                       P + st.first, DS.solve_tmap.p + st.tmap_off, st.stiles, 1,
                                        F->Lx.p, F->dLs.p, X, d, nr);
                 }
             }
@@ -772,6 +781,45 @@ int mi355_super_ltsolve_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
     int rc = check_handle(F);
     if (rc) return rc;
     return solve_dev(F, false, nrhs, X, d);
+}
+
+// zero the rows of X (n x nrhs entries of E doubles, leading dimension d) whose supernode is not kept
+__global__ __launch_bounds__(256) void k_keep_rows(int64_t n, int nrhs, int E, const int32_t *__restrict__ supermap,
+                                                   const int8_t *__restrict__ keep, double *__restrict__ X, int64_t d)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || keep[supermap[k]]) return;
+    for (int j = 0; j < nrhs; j++)
+        for (int e = 0; e < E; e++) X[(k + (int64_t)j * d) * E + e] = 0.0;
+}
+
+int mi355_super_solve_phase_dev(mi355_factor *F, int part, int lower, int64_t nrhs, double *X, int64_t d)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_local || !F->part_top) return fail(MI355_INVALID, "mi355_factor_set_partition was not called");
+    if (part != 0 && part != 1) return fail(MI355_INVALID, "part must be 0 (own subtrees) or 1 (top)");
+    if (!X && F->sym.n > 0 && nrhs > 0) return fail(MI355_INVALID, "null X");
+    return solve_dev(F, lower != 0, nrhs, X, d, part == 0 ? F->part_local : F->part_top);
+}
+
+int mi355_solve_keep_rows_dev(mi355_factor *F, int64_t nrhs, double *X, int64_t d)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_local || !F->part_top) return fail(MI355_INVALID, "mi355_factor_set_partition was not called");
+    const int64_t n = F->sym.n;
+    if (nrhs < 0 || d < n) return fail(MI355_INVALID, "X and L dimensions must match");
+    if (n == 0 || nrhs == 0) return MI355_OK;
+    if (!X) return fail(MI355_INVALID, "null X");
+    if (nrhs > 0x3fffffff) return fail(MI355_TOO_LARGE, "nrhs too large");
+    hipLaunchKernelGGL(k_keep_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, F->stream, n, (int)nrhs, F->E,
+                       F->dSupermap.p, F->asm_mask.p, X, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
 }
 
 // Y(k,:) = B(Perm[k],:)  (gather: d_perm, CHOLMOD/Cholesky/cholmod_solve.c:689,

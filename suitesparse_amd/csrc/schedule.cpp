@@ -215,9 +215,10 @@ bool check_tile_table(const Schedule &sc, const Step &st)
 }
 
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
-                    const int8_t *mask)
+                    const int8_t *mask, int64_t dinv_base)
 {
     out = Schedule();
+    out.dinv_size = dinv_base;
     const int64_t ns = S.nsuper;
     out.s_limit = s_limit;
     out.nscol2_limit = nscol2_limit;

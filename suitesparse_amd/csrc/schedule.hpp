@@ -129,8 +129,10 @@ std::string validate_symbolic(const Symbolic &S);
 // nscol2_limit columns (0: not at all), later supernodes not at all.
 // mask (optional, nsuper entries): only supernodes with mask[s] != 0 get their panel factorized
 // and push their updates -- the multi-GPU phases (own subtrees / shared top) of SURVEY 8(e).
+// dinv_base: first Dinv slot this schedule may use (two masked schedules of one factor keep their block
+// inverses side by side, so that the solves can use both).
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
-                    const int8_t *mask = nullptr);
+                    const int8_t *mask = nullptr, int64_t dinv_base = 0);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
 struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; };

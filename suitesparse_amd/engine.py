@@ -34,6 +34,7 @@ EXPORTS = [
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
+    "mi355_super_solve_phase_dev", "mi355_solve_keep_rows_dev",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
 ]
@@ -85,6 +86,8 @@ def lib():
         L.mi355_factor_set_partition.argtypes = [C.c_void_p, _i8p, _i8p, _i8p]
         L.mi355_factor_numeric_phase.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int64),
                                                  C.POINTER(C.c_int64)]
+        L.mi355_super_solve_phase_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_solve_keep_rows_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -286,6 +289,15 @@ class SupernodalFactor:
         info = C.c_int64(0)
         _check(lib().mi355_factor_numeric_phase(self._h, int(phase), float(beta), C.byref(bad), C.byref(info)))
         return int(bad.value), int(info.value)
+
+    def solve_phase_dev(self, part, lower, X_ptr, nrhs, d):
+        """one sweep over the supernodes of part 0 (own subtrees) / 1 (top) of a partitioned factor"""
+        _check(lib().mi355_super_solve_phase_dev(self._h, int(part), int(bool(lower)), int(nrhs),
+                                                 C.c_void_p(int(X_ptr)), int(d)))
+
+    def keep_rows_dev(self, X_ptr, nrhs, d):
+        """zero the rows of X outside this rank's asm_mask (before a sum over the ranks)"""
+        _check(lib().mi355_solve_keep_rows_dev(self._h, int(nrhs), C.c_void_p(int(X_ptr)), int(d)))
 
     def top_tensors(self, ranges):
         """torch views of Lx[lo:hi) for each (lo, hi) (device memory, no copy)"""

@@ -14,6 +14,9 @@ this is new work.  One process per GPU:
      top supernodes are coalesced into a single range).
   4. phase 1: every rank factorizes the top supernodes (replicated).
 
+Solves on the partitioned factor (PartitionedFactor.lsolve / ltsolve): the sweeps over the own subtrees run
+locally, the top sweeps replicated; ONE sum all-reduce of X joins the ranks' rows per sweep.
+
 No collective sits inside the data path of a subtree.  The replicated top bounds the speed-up
 (SURVEY Appendix A.3); distributing the top fronts block-cyclically is the next step.
 """
@@ -152,3 +155,25 @@ class PartitionedFactor:
         bad, info = self.f.numeric_phase(1, beta)
         self._agree(bad, info)
         return self.status
+
+    # ---- solves: X is a torch tensor holding n x nrhs entries column-major (leading dimension n), the
+    # same right-hand sides on every rank on entry, the same solution on every rank on return
+    def _sum(self, X):
+        if self.world > 1:
+            self.allreduce([X])
+
+    def lsolve(self, X, nrhs):
+        """L x = b (cholmod_super_lsolve): own subtrees, sum over the ranks, top"""
+        assert self.status == 0, "no positive-definite factor"
+        self.f.keep_rows_dev(X.data_ptr(), nrhs, self.n)
+        self.f.solve_phase_dev(0, True, X.data_ptr(), nrhs, self.n)
+        self._sum(X)
+        self.f.solve_phase_dev(1, True, X.data_ptr(), nrhs, self.n)
+
+    def ltsolve(self, X, nrhs):
+        """L' x = b (cholmod_super_ltsolve): top, own subtrees, union of the ranks' rows"""
+        assert self.status == 0, "no positive-definite factor"
+        self.f.solve_phase_dev(1, False, X.data_ptr(), nrhs, self.n)
+        self.f.solve_phase_dev(0, False, X.data_ptr(), nrhs, self.n)
+        self.f.keep_rows_dev(X.data_ptr(), nrhs, self.n)
+        self._sum(X)

@@ -181,13 +181,17 @@ int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int
 int emu_numeric_phase(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
                       const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
                       const double *Ax, double beta, const int8_t *proc_mask, const int8_t *asm_mask, int init,
-                      double *Lx, int64_t *first_bad, int64_t *info_out)
+                      double *Lx, int64_t *first_bad, int64_t *info_out,
+                      int64_t dinv_base, double *Dinv_out, int64_t *dinv_end)
 {
     Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
     S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
-    Schedule sc; build_schedule(S, nsuper, 0, sc, proc_mask);
+    Schedule sc; build_schedule(S, nsuper, 0, sc, proc_mask, dinv_base);
     std::vector<double> Dinv; std::vector<int> info;
     run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info, asm_mask, init != 0);
+    // the block inverses of this phase, kept by the caller for the solve phases (slots dinv_base ...)
+    if (Dinv_out) std::copy(Dinv.begin() + dinv_base, Dinv.begin() + sc.dinv_size, Dinv_out + dinv_base);
+    if (dinv_end) *dinv_end = sc.dinv_size;
     if (info[nsuper + 1] != 0) return -10;
     *first_bad = -1; *info_out = 0;
     for (int64_t s = 0; s < nsuper; s++) if (info[s]) { *first_bad = s; *info_out = info[s]; break; }
@@ -204,13 +208,15 @@ int64_t emu_dinv_size(int64_t n, int64_t nsuper, const int64_t *Super, const int
 }
 
 // the solve sweeps exactly as engine.hip's solve_dev walks the POTRF steps
-int emu_super_solve(int lower, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+// (proc_mask, dinv_base): the sweep over one masked schedule of a partitioned factor
+// (mi355_super_solve_phase_dev); nullptr, 0: the whole factor
+int emu_solve_phase(int lower, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
                     const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
-                    const double *Dinv, int64_t nrhs, double *X, int64_t d)
+                    const double *Dinv, int64_t nrhs, double *X, int64_t d, const int8_t *proc_mask, int64_t dinv_base)
 {
     Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
     S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
-    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    Schedule sc; build_schedule(S, nsuper, 0, sc, proc_mask, dinv_base);
     std::vector<const Step *> ps;
     for (const Step &st : sc.steps) if (st.kind == STEP_POTRF) ps.push_back(&st);
     if (!lower) std::reverse(ps.begin(), ps.end());
@@ -253,5 +259,12 @@ int emu_super_solve(int lower, int64_t n, int64_t nsuper, const int64_t *Super, 
         }
     }
     return 0;
+}
+
+int emu_super_solve(int lower, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                    const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
+                    const double *Dinv, int64_t nrhs, double *X, int64_t d)
+{
+    return emu_solve_phase(lower, n, nsuper, Super, Lpi, Lpx, Ls, ssize, xsize, Lx, Dinv, nrhs, X, d, nullptr, 0);
 }
 }

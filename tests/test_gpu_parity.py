@@ -235,6 +235,49 @@ def test_multigpu_phases_simulated_on_one_gpu(engine, world):
             if owner[s] in (r, -1):
                 a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
                 assert relerr(Lx[a:b], Lo[a:b]) < TOL_L
+    # solves on the partitioned factor (mi355_super_solve_phase_dev / mi355_solve_keep_rows_dev): scalar
+    # kernels (nrhs = 3) and MFMA sweeps (nrhs = 16), the sums over the ranks done by hand
+    n = g["n"]
+    for f in facs:
+        f.status = 0
+    for nrhs in (3, 16):
+        B = np.random.default_rng(nrhs).standard_normal((nrhs, n))
+        want_l = port.super_solve(g, Lo, B.T.copy(), lower=True).T
+        want_lt = port.super_solve(g, Lo, want_l.T.copy(), lower=False).T
+        Xs = [torch.from_numpy(B.copy()).cuda() for _ in range(world)]
+
+        def summed():
+            torch.cuda.synchronize()
+            tot = sum(Xs)
+            for x in Xs:
+                x.copy_(tot)
+            torch.cuda.synchronize()
+        for f, x in zip(facs, Xs):
+            f.f.keep_rows_dev(x.data_ptr(), nrhs, n)
+            f.f.solve_phase_dev(0, True, x.data_ptr(), nrhs, n)
+        summed()
+        for f, x in zip(facs, Xs):
+            f.f.solve_phase_dev(1, True, x.data_ptr(), nrhs, n)
+            assert relerr(x.cpu().numpy(), want_l) < 1e-10
+        for f, x in zip(facs, Xs):
+            f.f.solve_phase_dev(1, False, x.data_ptr(), nrhs, n)
+            f.f.solve_phase_dev(0, False, x.data_ptr(), nrhs, n)
+            f.f.keep_rows_dev(x.data_ptr(), nrhs, n)
+        summed()
+        for x in Xs:
+            assert relerr(x.cpu().numpy(), want_lt) < 1e-10
+    # world = 1 through the same driver: lsolve + ltsolve of PartitionedFactor
+    if world == 2:
+        L1 = engine.SupernodalFactor(g)
+        L1.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        run1 = multigpu.PartitionedFactor(L1, g, 0, 1)
+        assert run1.numeric() == 0
+        b = np.random.default_rng(9).standard_normal((2, n))
+        X = torch.from_numpy(b.copy()).cuda()
+        run1.lsolve(X, 2)
+        run1.ltsolve(X, 2)
+        want = port.super_solve(g, Lo, port.super_solve(g, Lo, b.T.copy(), lower=True), lower=False).T
+        assert relerr(X.cpu().numpy(), want) < 1e-10
 
 
 def test_zomplex_input_gives_complex_factor(engine):

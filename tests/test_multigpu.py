@@ -25,21 +25,45 @@ class EmuFactor:
         self.E = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
         self.E.emu_numeric_phase.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
                                              i64p, i64p, f64p, C.c_double, i8p, i8p, C.c_int, f64p,
-                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, f64p,
+                                             C.POINTER(C.c_int64)]
+        self.E.emu_solve_phase.argtypes = [C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64,
+                                           C.c_int64, f64p, f64p, C.c_int64, C.c_void_p, C.c_int64, i8p, C.c_int64]
+        self.E.emu_dinv_size.restype = C.c_int64
+        self.E.emu_dinv_size.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64]
         self.Lx = np.zeros(g["xsize"])
+        self.Dinv = np.zeros(self.E.emu_dinv_size(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"],
+                                                  g["ssize"], g["xsize"]) + 1)
+        self.dinv_local_end = 0
 
     def set_partition(self, local, top, asm):
         self.local, self.top, self.asm = (np.ascontiguousarray(m, dtype=np.int8) for m in (local, top, asm))
 
     def numeric_phase(self, phase, beta=0.0):
         g = self.g
-        bad, info = C.c_int64(-1), C.c_int64(0)
+        bad, info, end = C.c_int64(-1), C.c_int64(0), C.c_int64(0)
         rc = self.E.emu_numeric_phase(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"],
                                       g["xsize"], g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64),
                                       beta, self.local if phase == 0 else self.top, self.asm, int(phase == 0),
-                                      self.Lx, C.byref(bad), C.byref(info))
+                                      self.Lx, C.byref(bad), C.byref(info),
+                                      0 if phase == 0 else self.dinv_local_end, self.Dinv, C.byref(end))
         assert rc == 0
+        if phase == 0:
+            self.dinv_local_end = int(end.value)
         return int(bad.value), int(info.value)
+
+    def solve_phase_dev(self, part, lower, X_ptr, nrhs, d):
+        g = self.g
+        rc = self.E.emu_solve_phase(int(lower), g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"],
+                                    g["ssize"], g["xsize"], self.Lx, self.Dinv, nrhs, C.c_void_p(X_ptr), d,
+                                    self.local if part == 0 else self.top, 0 if part == 0 else self.dinv_local_end)
+        assert rc == 0
+
+    def keep_rows_dev(self, X_ptr, nrhs, d):
+        g = self.g
+        X = np.ctypeslib.as_array(C.cast(C.c_void_p(X_ptr), C.POINTER(C.c_double)), shape=(nrhs, d))
+        supermap = np.repeat(np.arange(g["nsuper"]), np.diff(g["Super"]))
+        X[:, :g["n"]][:, self.asm[supermap] == 0] = 0.0
 
     def top_tensors(self, ranges):
         import torch
@@ -117,6 +141,57 @@ def test_phases_with_simulated_ranks_match_oracle(kind, size, world):
                 assert relerr(f.Lx[a:b], Lo[a:b]) < 1e-11, (r, s)
 
 
+@pytest.mark.parametrize("kind,size,world,nrhs", [("lap3d", 12, 2, 1), ("lap3d", 12, 4, 3), ("lap2d", 40, 8, 2)])
+def test_solve_phases_with_simulated_ranks(kind, size, world, nrhs):
+    """lsolve / ltsolve on the partitioned factor: local sweeps + sum over the ranks + replicated top
+    sweeps give L^-1 b and L^-T b of the oracle's factor on every rank"""
+    import torch
+    from oracle import port
+    g = problem(kind, size)
+    n = g["n"]
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    facs = [EmuFactor(g) for _ in range(world)]
+    X = [None] * world
+
+    def allreduce(tensors):          # simulated ranks run one after the other: the sum is taken below
+        pass
+    runners = [multigpu.PartitionedFactor(f, g, r, world, allreduce=allreduce) for r, f in enumerate(facs)]
+    for rn in runners:
+        assert rn.f.numeric_phase(0) == (-1, 0)
+    for lo, hi in runners[0].part["top_ranges"]:
+        tot = sum(f.Lx[lo:hi] for f in facs)
+        for f in facs:
+            f.Lx[lo:hi] = tot
+    for rn in runners:
+        assert rn.f.numeric_phase(1) == (-1, 0)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((nrhs, n))
+    want_l = port.super_solve(g, Lo, B.T.copy(), lower=True).T
+    want_lt = port.super_solve(g, Lo, want_l.T.copy(), lower=False).T
+    Xs = [torch.from_numpy(B.copy()) for _ in range(world)]
+
+    def summed():
+        tot = sum(x.numpy() for x in Xs)
+        for x in Xs:
+            x.numpy()[...] = tot
+    # forward: keep_rows + local sweep, sum, top sweep
+    for rn, x in zip(runners, Xs):
+        rn.f.keep_rows_dev(x.data_ptr(), nrhs, n)
+        rn.f.solve_phase_dev(0, True, x.data_ptr(), nrhs, n)
+    summed()
+    for rn, x in zip(runners, Xs):
+        rn.f.solve_phase_dev(1, True, x.data_ptr(), nrhs, n)
+        assert relerr(x.numpy(), want_l) < 1e-11
+    # backward: top sweep, local sweep, keep_rows, sum
+    for rn, x in zip(runners, Xs):
+        rn.f.solve_phase_dev(1, False, x.data_ptr(), nrhs, n)
+        rn.f.solve_phase_dev(0, False, x.data_ptr(), nrhs, n)
+        rn.f.keep_rows_dev(x.data_ptr(), nrhs, n)
+    summed()
+    for x in Xs:
+        assert relerr(x.numpy(), want_lt) < 1e-11
+
+
 WORKER = r'''
 import os, sys
 import numpy as np
@@ -138,6 +213,14 @@ for s in range(g["nsuper"]):
     if owner[s] in (rank, -1):
         a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
         worst = max(worst, float(np.abs(f.Lx[a:b] - Lo[a:b]).max() / np.abs(Lo).max()))
+# solves on the partitioned factor: every rank ends with the oracle's L^-T L^-1 b
+rng = np.random.default_rng(3)
+b = rng.standard_normal((2, g["n"]))
+X = torch.from_numpy(b.copy())
+run.lsolve(X, 2)
+run.ltsolve(X, 2)
+want = port.super_solve(g, Lo, port.super_solve(g, Lo, b.T.copy(), lower=True), lower=False).T
+worst = max(worst, float(np.abs(X.numpy() - want).max() / np.abs(want).max()))
 # not positive definite: every rank must agree on status and minor
 g2 = dict(g); Sx = g["Sx"].copy(); col = int(g["n"] // 2); Sx[g["Sp"][col]] = -5.0; g2["Sx"] = Sx
 f2 = tm.EmuFactor(g2)
