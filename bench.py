@@ -170,7 +170,8 @@ def main():
     if big_ms > 0 and big_n > 0:
         # Common->fl counts a complex multiply-add as 2 flops; the MFMA pipe runs it as 8 real ones
         # (4 real products through the real view), so the roofline of a complex factor is priced in real flops
-        alg_per_launch = sym["fl"] * share / big_n * (4 if cplx else 1)
+        # N > 1: this rank's launches carry its share of those flops (own subtrees + its blocks of the top)
+        alg_per_launch = sym["fl"] * share * (st["flops_gemm128_here"] / f128) / big_n * (4 if cplx else 1)
         mean_s = big_ms * 1e-3 / big_n
         ach = alg_per_launch / mean_s * 1e-12
         roof.update(achieved=round(ach, 3), frac=round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
@@ -198,7 +199,9 @@ def main():
                    "n": p["n"], "fl": sym["fl"], "lnz": sym["lnz"], "nsuper": sym["nsuper"],
                    "xsize": sym["xsize"], "levels": int(st["nlevels"]), "update_pairs": int(st["npairs"]),
                    "exec_flops": {"update": st["flops_update"], "panel": st["flops_panel"]},
-                   "parallelism": "1 GPU" if world == 1 else f"subtree-to-GPU x{world} + replicated top",
+                   "parallelism": "1 GPU" if world == 1 else
+                   f"subtree-to-GPU x{world} + " + ("owner-computes top (1024-column blocks, broadcasts)"
+                                                    if runner.dist else "replicated top"),
                    "analyze_s": round(t_analyze, 2), "setup_s": round(t_setup, 2),
                    "frac_fp64_mfma_peak": round(gflops * 1e-3 * (4 if cplx else 1)
                                                 / (FP64_MFMA_PEAK_TFLOPS * world), 4),

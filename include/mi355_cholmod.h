@@ -115,6 +115,24 @@ int mi355_factor_set_partition(mi355_factor *handle, const int8_t *local_mask,
 int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,
                                int64_t *first_bad, int64_t *info);
 
+/* The top, owner-computes instead of replicated (no counterpart in the reference).  After set_partition:
+ *   mi355_factor_set_top_distribution(h, rank, world): the columns of every top supernode are cut into outer
+ *     blocks (tuning key 7 wide); block (s, jb) has one owner, who alone factorizes it and applies the updates
+ *     that target it; a finished block is broadcast from its owner before anybody reads it.
+ *   mi355_factor_top_plan: the broadcasts, in the order every rank issues them -- `count` rows of 4 int64
+ *     (step, lo, n, root): entries Lx[lo, lo+n) of mi355_factor_device_Lx from rank `root`; and the range
+ *     [dinv_lo, dinv_hi) of block inverses (entries of mi355_factor_device_Dinv) to SUM over the ranks after
+ *     the last segment, for the solves.  plan may be NULL to ask for count only.
+ *   mi355_factor_top_run(h, seg): the launches between broadcast seg-1 and broadcast seg (seg = 0 .. count;
+ *     returns when they have finished).  seg = count also reports the first failed pivot like numeric_phase.
+ * Per factorization: numeric_phase(0); all-reduce the top panels; for seg in 0..count-1: top_run(seg),
+ * broadcast seg; top_run(count); all-reduce Dinv[dinv_lo, dinv_hi).  (suitesparse_amd/multigpu.py) */
+int mi355_factor_set_top_distribution(mi355_factor *handle, int rank, int world);
+int mi355_factor_top_plan(mi355_factor *handle, int64_t cap, int64_t *plan, int64_t *count,
+                          int64_t *dinv_lo, int64_t *dinv_hi);
+int mi355_factor_top_run(mi355_factor *handle, int64_t seg, int64_t *first_bad, int64_t *info);
+double *mi355_factor_device_Dinv(mi355_factor *handle);
+
 /* Solves on a partitioned factor (after both phases succeeded on every rank; no counterpart in the
  * reference).  X is a device pointer, n x nrhs entries, leading dimension d, as in mi355_super_lsolve_dev.
  *   mi355_super_solve_phase_dev: the forward (lower != 0) or backward sweep over the supernodes of one
@@ -198,7 +216,8 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *            15 reserved
  *            16 ms in k_gemm128 launches (part of 1)      17 number of k_gemm128 launches
  *            18 useful flops of the tasks in k_gemm128    19 useful flops of the tasks in k_gemm64
- *            20 k_gemm128 tiles per factorization         21 k_gemm64 tiles        22-23 reserved */
+ *            20 k_gemm128 tiles per factorization         21 k_gemm64 tiles
+ *            22 useful k_gemm128 flops this handle executes (its share of a partition)   23 reserved */
 int mi355_factor_get_stats(mi355_factor *handle, double *out24);
 
 /* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device` (no counterpart in the reference;

@@ -99,6 +99,8 @@ struct mi355_factor_s {
     DeviceSchedule full;
     // multi-GPU partition: own subtrees / shared top, see mi355_factor_set_partition
     DeviceSchedule *part_local = nullptr, *part_top = nullptr;
+    DeviceSchedule *part_dist = nullptr;   // the top, owner-computes over the ranks (mi355_factor_set_top_distribution)
+    std::vector<int8_t> top_mask_host;
     DevBuf<int8_t> asm_mask;
     // staged matrix
     DevBuf<int64_t> Ap, Ai, Anz;
@@ -198,7 +200,7 @@ struct EventTimer {
 
 // run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
 int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm,
-                 const int8_t *smask = nullptr, bool init = true)
+                 const int8_t *smask = nullptr, bool init = true, int64_t step0 = 0, int64_t step1 = -1)
 {
     const Symbolic &S = F->sym;
     tm.begin(2);
@@ -221,7 +223,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     hipEvent_t le0 = nullptr, le1 = nullptr;
     if (steplog) { (void)hipEventCreate(&le0); (void)hipEventCreate(&le1); }
     struct LogCloser { FILE *&f; hipEvent_t &a, &b; ~LogCloser() { if (f) { fclose(f); (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } } closer{steplog, le0, le1};
-    for (const Step &st : D.sched.steps) {
+    if (step1 < 0) step1 = (int64_t)D.sched.steps.size();
+    for (int64_t si = step0; si < step1; si++) {
+        const Step &st = D.sched.steps[(size_t)si];
         if (st.count <= 0) continue;
         if (steplog) (void)hipEventRecord(le0, F->stream);
         if (st.kind == STEP_POTRF) {
@@ -375,6 +379,7 @@ int mi355_factor_free(mi355_factor *F)
     if (F->timer) { F->timer->drop(); delete F->timer; }
     delete F->part_local;
     delete F->part_top;
+    delete F->part_dist;
     delete F;
     return MI355_OK;
 }
@@ -539,6 +544,8 @@ int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const 
         if (local_mask[s] && top_mask[s]) return fail(MI355_INVALID, "a supernode is both local and top");
     delete F->part_local; F->part_local = nullptr;
     delete F->part_top; F->part_top = nullptr;
+    delete F->part_dist; F->part_dist = nullptr;
+    F->top_mask_host.assign(top_mask, top_mask + S.nsuper);
     F->part_local = new DeviceSchedule;
     F->part_top = new DeviceSchedule;
     build_schedule(S, S.nsuper, 0, F->part_local->sched, local_mask);
@@ -603,6 +610,108 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     }
     return MI355_OK;
 }
+
+int mi355_factor_set_top_distribution(mi355_factor *F, int rank, int world)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_local || !F->part_top) return fail(MI355_INVALID, "mi355_factor_set_partition was not called");
+    if (world < 1 || rank < 0 || rank >= world) return fail(MI355_INVALID, "rank/world out of range");
+    const Symbolic &S = F->sym;
+    delete F->part_dist; F->part_dist = nullptr;
+    F->part_dist = new DeviceSchedule;
+    DistTop dt; dt.rank = rank; dt.world = world;
+    build_schedule(S, S.nsuper, 0, F->part_dist->sched, F->top_mask_host.data(), F->part_local->sched.dinv_size, &dt);
+    if (F->part_dist->sched.dinv_size != F->part_top->sched.dinv_size)
+        return fail(MI355_GPU_PROBLEM, "internal: Dinv slots of the distributed top differ from the replicated top's");
+    F->part_ok = false;
+    return upload_schedule(F, *F->part_dist);
+}
+
+int mi355_factor_top_plan(mi355_factor *F, int64_t cap, int64_t *plan, int64_t *count, int64_t *dinv_lo, int64_t *dinv_hi)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_dist) return fail(MI355_INVALID, "mi355_factor_set_top_distribution was not called");
+    if (!count) return fail(MI355_INVALID, "null count");
+    const Schedule &sc = F->part_dist->sched;
+    *count = (int64_t)sc.bcasts.size();
+    if (dinv_lo) *dinv_lo = F->part_local->sched.dinv_size;
+    if (dinv_hi) *dinv_hi = sc.dinv_size;
+    if (!plan) return MI355_OK;
+    if (cap < *count) return fail(MI355_INVALID, "plan buffer too small");
+    for (size_t i = 0; i < sc.bcasts.size(); i++) {
+        plan[4 * i] = sc.bcasts[i].step; plan[4 * i + 1] = sc.bcasts[i].lo;
+        plan[4 * i + 2] = sc.bcasts[i].count; plan[4 * i + 3] = sc.bcasts[i].root;
+    }
+    return MI355_OK;
+}
+
+int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64_t *info_out)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!F->part_dist) return fail(MI355_INVALID, "mi355_factor_set_top_distribution was not called");
+    if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
+    const Symbolic &S = F->sym;
+    const Schedule &sc = F->part_dist->sched;
+    const int64_t nb = (int64_t)sc.bcasts.size();
+    if (seg < 0 || seg > nb) return fail(MI355_INVALID, "segment out of range");
+    if (first_bad) *first_bad = -1;
+    if (info_out) *info_out = 0;
+    F->part_ok = false;
+    if (S.nsuper == 0) return MI355_OK;
+    if (!F->timer) F->timer = new EventTimer;
+    EventTimer &tm = *F->timer;
+    tm.on = F->profile != 0;
+    tm.st = F->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, F->stream));
+    if (seg == 0) {
+        // the block inverses of the blocks other ranks own stay zero: a sum over the ranks completes them
+        const int64_t lo = F->part_local->sched.dinv_size, hi = sc.dinv_size;
+        if (hi > lo) HIP_TRY(hipMemsetAsync(F->Dinv.p + lo * F->E, 0, (size_t)(hi - lo) * F->E * sizeof(double), F->stream));
+    }
+    const int64_t step0 = seg == 0 ? 0 : sc.bcasts[(size_t)seg - 1].step;
+    const int64_t step1 = seg == nb ? (int64_t)sc.steps.size() : sc.bcasts[(size_t)seg].step;
+    rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, step1);
+    if (rc) return rc;
+    int sf = 0x7f7f7f7f;
+    const int big = 0x7f7f7f7f;
+    if (seg == nb) {
+        int *first = F->info.p + S.nsuper;
+        HIP_TRY(hipMemsetAsync(first, 0x7f, sizeof(int), F->stream));
+        hipLaunchKernelGGL(k_first_info, dim3((unsigned)((S.nsuper + 255) / 256)), dim3(256), 0, F->stream,
+                           S.nsuper, F->info.p, first);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&sf, first, sizeof(int), hipMemcpyDeviceToHost, F->stream));
+    }
+    HIP_TRY(hipEventRecord(e1, F->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    F->st_total += ms;
+    tm.pending = tm.on;
+    if (seg == nb) {
+        if (sf != big) {
+            int info = 0;
+            HIP_TRY(hipMemcpy(&info, F->info.p + sf, sizeof(int), hipMemcpyDeviceToHost));
+            if (first_bad) *first_bad = sf;
+            if (info_out) *info_out = info;
+        } else {
+            F->part_ok = true;  // the caller vouches for every rank having succeeded (and for the Dinv sum)
+        }
+    }
+    return MI355_OK;
+}
+
+double *mi355_factor_device_Dinv(mi355_factor *F) { return F ? F->Dinv.p : nullptr; }
 
 // part == nullptr: the whole factor; else the sweeps over one masked schedule of a partitioned factor
 static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr)
@@ -1135,7 +1244,11 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
     out[11] = (double)S.relmap_size; out[12] = (double)S.dinv_size; out[13] = F->st_solve;
     out[14] = F->st_tiles; out[15] = 0;
     out[16] = F->st_big; out[17] = F->st_nbig; out[18] = S.flops_big; out[19] = S.flops_small;
-    out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[22] = 0; out[23] = 0;
+    out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[23] = 0;
+    // useful k_gemm128 flops THIS handle executes per factorization: all of them, or its share of a partition
+    out[22] = S.flops_big;
+    if (F->part_local && F->part_top)
+        out[22] = F->part_local->sched.flops_big + (F->part_dist ? F->part_dist->sched.flops_big : F->part_top->sched.flops_big);
     return MI355_OK;
 }
 

@@ -74,9 +74,14 @@ struct LevelSteps {
     std::vector<std::vector<PotrfTask>> potrf;
     std::vector<std::vector<GemmTask>> trsm, trail;
     std::vector<GemmTask> updates;
+    // DistTop: is potrf[it][i] (and its trsm task) this rank's; blocks that complete at iteration it
+    std::vector<std::vector<int8_t>> mine;
+    std::vector<std::vector<BcastPoint>> bcast;
     void ensure(size_t it)
     {
-        if (potrf.size() <= it) { potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); }
+        if (potrf.size() <= it) {
+            potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); mine.resize(it + 1); bcast.resize(it + 1);
+        }
     }
 };
 
@@ -215,7 +220,7 @@ bool check_tile_table(const Schedule &sc, const Step &st)
 }
 
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
-                    const int8_t *mask, int64_t dinv_base)
+                    const int8_t *mask, int64_t dinv_base, const DistTop *dist)
 {
     out = Schedule();
     out.dinv_size = dinv_base;
@@ -251,6 +256,32 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     out.nlevels = nlev;
 
     std::vector<LevelSteps> L(nlev);
+
+    // DistTop: owner of outer block jb of masked supernode s = (position of s among the masked supernodes of
+    // its level + jb * their number + level) mod world -- blocks that are worked on at the same time (same
+    // level, same jb) and consecutive blocks of one supernode land on different ranks
+    if (dist && (!mask || truncated || dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world)) dist = nullptr;
+    std::vector<int32_t> pos_in_level, n_in_level;
+    if (dist) {
+        pos_in_level.assign(ns, 0);
+        n_in_level.assign(nlev, 0);
+        for (int64_t s = 0; s < ns; s++)
+            if (mask[s]) pos_in_level[s] = n_in_level[out.level[s]]++;
+    }
+    auto owner = [&](int64_t s, int64_t jb) {
+        const int lev = out.level[s];
+        return (int32_t)(((int64_t)pos_in_level[s] + jb * n_in_level[lev] + lev) % dist->world);
+    };
+    // widest nested block width (the unit of ownership)
+    int64_t WB = NB;
+    {
+        const int64_t w1 = std::max(NB, (tuning().ob / NB) * NB);
+        if (w1 > WB) WB = w1;
+        const int64_t w2 = (tuning().ob2 / NB) * NB;
+        if (w2 > WB && w2 % WB == 0) WB = w2;
+        const int64_t w3 = (tuning().ob3 / NB) * NB;
+        if (w3 > WB && w3 % WB == 0) WB = w3;
+    }
 
     for (int64_t s = 0; s < s_end; s++) {
         if (mask && !mask[s]) continue;
@@ -288,15 +319,25 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
             pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
             pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
+            const bool own = !dist || owner(s, j / WB) == dist->rank;
             L[lev].potrf[it].push_back(pt);
-            out.flops_panel += (double)nb * nb * nb / 3.0;
+            L[lev].mine[it].push_back(own ? 1 : 0);
+            if (own) out.flops_panel += (double)nb * nb * nb / 3.0;
+            if (dist && e == std::min<int64_t>((j / WB) * WB + WB, ncol_eff)) {
+                // outer block (s, j / WB) is complete after this iteration's TRSM: its columns go to everybody
+                const int64_t b0 = (j / WB) * WB;
+                BcastPoint bp;
+                bp.step = -1; bp.lo = psx + b0 * nsrow; bp.count = (e - b0) * nsrow;
+                bp.root = owner(s, j / WB); bp.s = (int32_t)s;
+                L[lev].bcast[it].push_back(bp);
+            }
             if (below <= 0) continue;
             // X = B * inv(L11)^H  (trsm "R","L","C","N", worker :1175)
             GemmTask t = make_gemm(psx + e + j * nsrow, /*b: slot, set later*/ 0,
                                    psx + e + j * nsrow, -1, nsrow, nb, nsrow,
                                    below, nb, nb, GEMM_OVERWRITE);
             L[lev].trsm[it].push_back(t);
-            out.flops_panel += (double)below * nb * nb;
+            if (own) out.flops_panel += (double)below * nb * nb;
             for (size_t lvl = 0; lvl < W.size(); lvl++) {
                 const int64_t b0 = ((e - 1) / W[lvl]) * W[lvl];                       // block of this level ending at e?
                 if (std::min<int64_t>(b0 + W[lvl], ncol_eff) != e) break;
@@ -304,6 +345,21 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     ? std::min<int64_t>((b0 / W[lvl + 1]) * W[lvl + 1] + W[lvl + 1], ncol_eff) : ncol_eff;
                 if (enc_end <= e) continue;                                           // enclosing block complete too
                 const int64_t K = e - b0, Nn = enc_end - e;
+                if (dist && lvl + 1 == W.size()) {
+                    // outermost update, owner-computes: one task per target outer block, kept by its owner
+                    for (int64_t c0 = e; c0 < ncol_eff; c0 += WB) {
+                        const int64_t c1 = std::min<int64_t>(c0 + WB, ncol_eff);
+                        if (owner(s, c0 / WB) != dist->rank) continue;
+                        L[lev].trail[it].push_back(make_gemm(
+                            psx + c0 + b0 * nsrow, psx + c0 + b0 * nsrow,
+                            psx + c0 + c0 * nsrow, -1, nsrow, nsrow, nsrow,
+                            nsrow - c0, c1 - c0, K, GEMM_DIRECT_SUB));
+                        const double Nt = (double)(c1 - c0), Mt = (double)(nsrow - c0);
+                        out.flops_panel += (Nt * Nt + 2.0 * (Mt - Nt) * Nt) * (double)K;
+                    }
+                    break;
+                }
+                if (!own) break;
                 L[lev].trail[it].push_back(make_gemm(
                     psx + e + b0 * nsrow, psx + e + b0 * nsrow,
                     psx + e + e * nsrow, -1, nsrow, nsrow, nsrow,
@@ -332,6 +388,26 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 up.rm_off = out.relmap_size;
                 out.relmap_size += ndrow2;
                 out.pairs.push_back(up);
+                if (dist) {
+                    // owner-computes: the rows [p, q) of s are cut where their column of anc enters another
+                    // outer block; each piece updates ONE block of anc and runs on that block's owner
+                    int64_t p1 = p;
+                    while (p1 < q) {
+                        const int64_t tb = (S.Ls[p1] - S.Super[anc]) / WB;
+                        int64_t q1 = p1;
+                        while (q1 < q && (S.Ls[q1] - S.Super[anc]) / WB == tb) q1++;
+                        if (owner(anc, tb) == dist->rank) {
+                            const int64_t a1 = psx + (p1 - pdi), n1 = q1 - p1, m1 = pdend - p1;
+                            L[lev].updates.push_back(make_gemm(a1, a1, S.Lpx[anc], up.rm_off + (p1 - p), nsrow, nsrow,
+                                                               up.nsrow, m1, n1, nscol, GEMM_SCATTER_SUB));
+                            out.flops_update += (double)n1 * n1 * nscol + 2.0 * (double)(m1 - n1) * n1 * nscol;
+                            out.bytes_assembly += (double)n1 * m1 * 8.0;
+                        }
+                        p1 = q1;
+                    }
+                    p = q;
+                    continue;
+                }
                 const int64_t a = psx + (p - pdi);
                 L[lev].updates.push_back(make_gemm(a, a, S.Lpx[anc], up.rm_off, nsrow, nsrow, up.nsrow,
                                                    ndrow2, ndrow1, nscol, GEMM_SCATTER_SUB));
@@ -352,19 +428,25 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             // Every block keeps its inverse for the whole life of the factor (the solves
             // reuse it): slots are global, sum nb^2 <= 64*n entries.
             size_t ti = 0;
-            for (auto &pt : ls.potrf[it]) {
+            std::vector<PotrfTask> pts;                 // the tasks this schedule runs (all, or this rank's)
+            std::vector<GemmTask> trs;
+            for (size_t i = 0; i < ls.potrf[it].size(); i++) {
+                PotrfTask &pt = ls.potrf[it][i];
                 const bool has_below = (pt.dinv_off >= 0);
+                const bool own = ls.mine[it][i] != 0;
                 pt.dinv_off = out.dinv_size;
                 if (has_below) {
                     ls.trsm[it][ti].b_off = pt.dinv_off;
+                    if (own) trs.push_back(ls.trsm[it][ti]);
                     ti++;
                 }
                 out.dinv_size += (int64_t)pt.nb * pt.nb;
+                if (own) pts.push_back(pt);
             }
             int64_t stiles = 0;
             const int64_t tmap_off = (int64_t)out.solve_tile_task.size();
             int32_t ti32 = 0;
-            for (auto &pt : ls.potrf[it]) {
+            for (auto &pt : pts) {
                 const int64_t below = (int64_t)pt.lda - (pt.col0 + pt.nb);
                 const int64_t nt = (below + SOLVE_ROWS - 1) / SOLVE_ROWS;
                 pt.stile0 = stiles;
@@ -375,13 +457,17 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             Step st;
             st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0;
             st.first = (int64_t)out.potrf.size();
-            st.count = (int64_t)ls.potrf[it].size();
+            st.count = (int64_t)pts.size();
             st.ntiles = st.count;
             st.stiles = stiles;
             st.tmap_off = tmap_off;
-            out.potrf.insert(out.potrf.end(), ls.potrf[it].begin(), ls.potrf[it].end());
+            out.potrf.insert(out.potrf.end(), pts.begin(), pts.end());
             if (st.count > 0) out.steps.push_back(st);
-            flush_gemm(out, ls.trsm[it], lev, S, 1);
+            flush_gemm(out, trs, lev, S, 1);
+            for (BcastPoint bp : ls.bcast[it]) {        // finished outer blocks, before anybody's update reads them
+                bp.step = (int64_t)out.steps.size();
+                out.bcasts.push_back(bp);
+            }
             flush_gemm(out, ls.trail[it], lev, S);
         }
         flush_gemm(out, ls.updates, lev, S);

@@ -88,7 +88,20 @@ struct Symbolic {
     bool cplx = false;          // complex factor: the big-tile kernel covers 64 x 128 complex entries per tile
 };
 
+// Owner-computes distribution of the masked (top) supernodes over `world` ranks (multi-GPU): the
+// columns of every such supernode are cut into outer blocks of the widest nested width (Tuning::ob2); block
+// (s, jb) has one owner, who alone factorizes it and applies every update that targets it.  A finished block
+// is then broadcast (BcastPoint) before anybody reads it.  The schedule of rank `rank` holds its tasks only.
+struct DistTop { int32_t rank = 0, world = 1; };
+struct BcastPoint {
+    int64_t step;       // the broadcast happens before steps[step] (after everything earlier)
+    int64_t lo, count;  // entries of Lx: the block's columns, contiguous
+    int32_t root;       // owner of the block
+    int32_t s;          // supernode
+};
+
 struct Schedule {
+    std::vector<BcastPoint> bcasts;     // DistTop schedules only, in the order every rank must issue them
     std::vector<int32_t> supermap;      // column -> supernode
     std::vector<int32_t> parent;        // supernodal etree (-1 = root)
     std::vector<int32_t> level;         // height above the leaves
@@ -131,8 +144,10 @@ std::string validate_symbolic(const Symbolic &S);
 // and push their updates -- the multi-GPU phases (own subtrees / shared top) of SURVEY 8(e).
 // dinv_base: first Dinv slot this schedule may use (two masked schedules of one factor keep their block
 // inverses side by side, so that the solves can use both).
+// dist (with a mask, full schedules only): the owner-computes schedule of one rank, see DistTop; the Dinv slots are
+// numbered as in the undistributed schedule of the same mask.
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
-                    const int8_t *mask = nullptr, int64_t dinv_base = 0);
+                    const int8_t *mask = nullptr, int64_t dinv_base = 0, const DistTop *dist = nullptr);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
 struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; };

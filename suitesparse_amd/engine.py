@@ -35,6 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_super_solve_phase_dev", "mi355_solve_keep_rows_dev",
+    "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
 ]
@@ -88,6 +89,12 @@ def lib():
                                                  C.POINTER(C.c_int64)]
         L.mi355_super_solve_phase_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
         L.mi355_solve_keep_rows_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_factor_set_top_distribution.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mi355_factor_top_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mi355_factor_top_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mi355_factor_device_Dinv.argtypes = [C.c_void_p]
+        L.mi355_factor_device_Dinv.restype = C.c_void_p
         _LIB = L
     return _LIB
 
@@ -130,7 +137,7 @@ def set_tuning(key, value):
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
              "flops_update", "flops_panel", "bytes_assembly", "npairs", "nlevels", "relmap_entries",
              "dinv_entries", "solve_ms", "gemm_tiles", "reserved", "gemm128_ms", "gemm128_launches",
-             "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "reserved2", "reserved3"]
+             "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "flops_gemm128_here", "reserved3"]
 
 
 class SupernodalFactor:
@@ -299,10 +306,29 @@ class SupernodalFactor:
         """zero the rows of X outside this rank's asm_mask (before a sum over the ranks)"""
         _check(lib().mi355_solve_keep_rows_dev(self._h, int(nrhs), C.c_void_p(int(X_ptr)), int(d)))
 
-    def top_tensors(self, ranges):
+    def set_top_distribution(self, rank, world):
+        """owner-computes top: returns (plan, (dinv_lo, dinv_hi)); plan rows = (step, lo, n, root)"""
+        _check(lib().mi355_factor_set_top_distribution(self._h, int(rank), int(world)))
+        cnt, lo, hi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().mi355_factor_top_plan(self._h, 0, None, C.byref(cnt), C.byref(lo), C.byref(hi)))
+        plan = np.zeros((cnt.value, 4), dtype=np.int64)
+        _check(lib().mi355_factor_top_plan(self._h, cnt.value, plan.ctypes.data_as(C.c_void_p), C.byref(cnt),
+                                           C.byref(lo), C.byref(hi)))
+        return plan, (int(lo.value), int(hi.value))
+
+    def top_run(self, seg):
+        """launches of the distributed top up to broadcast `seg`; (first_bad, info) after the last segment"""
+        bad, info = C.c_int64(-1), C.c_int64(0)
+        _check(lib().mi355_factor_top_run(self._h, int(seg), C.byref(bad), C.byref(info)))
+        return int(bad.value), int(info.value)
+
+    def dinv_tensors(self, ranges):
+        return self.top_tensors(ranges, base=lib().mi355_factor_device_Dinv(self._h))
+
+    def top_tensors(self, ranges, base=None):
         """torch views of Lx[lo:hi) for each (lo, hi) (device memory, no copy)"""
         import torch
-        base = self.device_Lx_ptr()
+        base = self.device_Lx_ptr() if base is None else base
         out = []
         for lo, hi in ranges:
             class _View:

@@ -12,14 +12,18 @@ this is new work.  One process per GPU:
      (rank 0's copy also holds the entries of A).
   3. ONE sum all-reduce over the Lx ranges of the top supernodes (RCCL over xGMI; adjacent
      top supernodes are coalesced into a single range).
-  4. phase 1: every rank factorizes the top supernodes (replicated).
+  4. the top: owner-computes by default -- the columns of each top supernode are cut into outer blocks
+     (1024 wide), block (s, jb) belongs to one rank, which alone factorizes it and applies the updates
+     that target it; a finished block is broadcast before it is read (mi355_factor_top_plan / _top_run).
+     The block inverses are summed over the ranks afterwards, so that every rank can run the top sweeps
+     of the solves.  (distribute_top=False or MI355_TOP=replicated: every rank factorizes the whole top.)
 
 Solves on the partitioned factor (PartitionedFactor.lsolve / ltsolve): the sweeps over the own subtrees run
 locally, the top sweeps replicated; ONE sum all-reduce of X joins the ranks' rows per sweep.
 
-No collective sits inside the data path of a subtree.  The replicated top bounds the speed-up
-(SURVEY Appendix A.3); distributing the top fronts block-cyclically is the next step.
-"""
+No collective sits inside the data path of a subtree.  """
+import os
+
 import numpy as np
 
 
@@ -44,7 +48,7 @@ def supernode_tree(sym):
     return parent, work
 
 
-def partition(sym, world, min_subtrees_per_rank=4):
+def partition(sym, world, min_subtrees_per_rank=2):
     """Returns dict(owner[nsuper] (-1 = top), top_ranges [(lo,hi) Lx offsets], stats)."""
     ns = int(sym["nsuper"])
     parent, work = supernode_tree(sym)
@@ -101,7 +105,8 @@ class PartitionedFactor:
     (or any object with set_partition / numeric_phase / top_tensors); `allreduce(tensors)` sums
     every tensor over the ranks (default: torch.distributed all_reduce = RCCL on GPUs)."""
 
-    def __init__(self, factor, sym, rank, world, allreduce=None, min_subtrees_per_rank=4):
+    def __init__(self, factor, sym, rank, world, allreduce=None, min_subtrees_per_rank=2, distribute_top=None,
+                 bcast=None):
         self.f, self.rank, self.world = factor, rank, world
         self.n = int(sym["n"])
         self.Super = sym["Super"]
@@ -115,7 +120,15 @@ class PartitionedFactor:
         factor.set_partition(local, top, asm)
         self.tensors = factor.top_tensors(self.part["top_ranges"])
         self.allreduce = allreduce or self._dist_allreduce
+        self.bcast = bcast or self._dist_bcast
         self.status, self.minor = 0, self.n
+        if distribute_top is None:
+            distribute_top = os.environ.get("MI355_TOP", "distributed") != "replicated"
+        self.dist = bool(distribute_top) and world > 1 and bool(self.part["top_ranges"])
+        if self.dist:
+            self.plan, (dlo, dhi) = factor.set_top_distribution(rank, world)
+            self.bviews = factor.top_tensors([(int(lo), int(lo + cnt)) for _, lo, cnt, _ in self.plan])
+            self.dinv_views = factor.dinv_tensors([(dlo, dhi)]) if dhi > dlo else []
 
     @staticmethod
     def _dist_allreduce(tensors):
@@ -128,6 +141,35 @@ class PartitionedFactor:
             # before the collective has finished on the communication stream
             import torch
             torch.cuda.synchronize()
+
+    @staticmethod
+    def _dist_bcast(tensor, root):
+        """enqueue the broadcast of one finished block from its owner (RCCL: returns once enqueued)"""
+        import torch.distributed as dist
+        dist.broadcast(tensor, src=int(root))
+
+    @staticmethod
+    def _comm_done(tensor):
+        if tensor.is_cuda:
+            # the engine launches on its own (non-blocking) HIP stream: the next segment must not start
+            # before the broadcasts have finished on the communication stream
+            import torch
+            torch.cuda.synchronize()
+
+    def _top_distributed(self):
+        """segments of launches (engine stream, finished when top_run returns) between the broadcasts"""
+        prev, pending = 0, None
+        for k, (step, lo, cnt, root) in enumerate(self.plan):
+            if k == 0 or step > prev:
+                if pending is not None:
+                    self._comm_done(pending)
+                    pending = None
+                self.f.top_run(k)
+            self.bcast(self.bviews[k], root)
+            pending, prev = self.bviews[k], step
+        if pending is not None:
+            self._comm_done(pending)
+        return self.f.top_run(len(self.plan))
 
     def _agree(self, bad, info):
         """smallest failing supernode over the ranks -> (status, minor)"""
@@ -152,8 +194,13 @@ class PartitionedFactor:
             return self.status
         if self.world > 1 and self.tensors:
             self.allreduce(self.tensors)
-        bad, info = self.f.numeric_phase(1, beta)
-        self._agree(bad, info)
+        if self.dist:
+            bad, info = self._top_distributed()
+            if self._agree(bad, info) < 0 and self.dinv_views:
+                self.allreduce(self.dinv_views)      # every rank gets every block inverse (solves)
+        else:
+            bad, info = self.f.numeric_phase(1, beta)
+            self._agree(bad, info)
         return self.status
 
     # ---- solves: X is a torch tensor holding n x nrhs entries column-major (leading dimension n), the

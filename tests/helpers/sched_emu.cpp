@@ -25,11 +25,13 @@ struct Emu {
 
 void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t *Ap, const int64_t *Ai,
          const double *Ax, double beta, double *Lx, std::vector<double> &Dinv, std::vector<int> &info,
-         const int8_t *asm_mask = nullptr, bool init = true)
+         const int8_t *asm_mask = nullptr, bool init = true, int64_t step0 = 0, int64_t step1 = -1,
+         bool keep_dinv = false)
 {
     if (init) std::fill(Lx, Lx + S.xsize, 0.0);
     info.assign(S.nsuper + 2, 0);
-    Dinv.assign(sc.dinv_size + 1, 0.0);
+    if (!keep_dinv) Dinv.assign(sc.dinv_size + 1, 0.0);
+    if (step1 < 0) step1 = (int64_t)sc.steps.size();
     for (int64_t k = 0; init && k < ncols_asm; k++) {
         int s = sc.supermap[k];
         if (asm_mask && !asm_mask[s]) continue;
@@ -47,7 +49,8 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
         for (int i = 0; i < u.ndrow2; i++)
             relmap[u.rm_off + i] = find_row(S.Ls + u.ls_dst, u.nsrow, S.Ls[u.ls_src + i]);
     std::vector<double> C;
-    for (const Step &st : sc.steps) {
+    for (int64_t si = step0; si < step1; si++) {
+        const Step &st = sc.steps[(size_t)si];
         if (st.kind == STEP_POTRF) {
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const PotrfTask &t = sc.potrf[ti];
@@ -196,6 +199,57 @@ int emu_numeric_phase(int64_t n, int64_t nsuper, const int64_t *Super, const int
     *first_bad = -1; *info_out = 0;
     for (int64_t s = 0; s < nsuper; s++) if (info[s]) { *first_bad = s; *info_out = info[s]; break; }
     return 0;
+}
+
+// owner-computes top (mi355_factor_top_plan / _top_run): the broadcast points of rank `rank`'s schedule
+// (4 int64 each: step, lo, count, root) and the number of steps
+int emu_top_plan(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                 const int64_t *Ls, int64_t ssize, int64_t xsize, const int8_t *top_mask, int rank, int world,
+                 int64_t dinv_base, int64_t cap, int64_t *plan, int64_t *count, int64_t *nsteps, int64_t *dinv_end)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    DistTop dt; dt.rank = rank; dt.world = world;
+    Schedule sc; build_schedule(S, nsuper, 0, sc, top_mask, dinv_base, &dt);
+    *count = (int64_t)sc.bcasts.size();
+    *nsteps = (int64_t)sc.steps.size();
+    *dinv_end = sc.dinv_size;
+    if (*count > cap) return -20;
+    for (size_t i = 0; i < sc.bcasts.size(); i++) {
+        plan[4 * i] = sc.bcasts[i].step; plan[4 * i + 1] = sc.bcasts[i].lo;
+        plan[4 * i + 2] = sc.bcasts[i].count; plan[4 * i + 3] = sc.bcasts[i].root;
+    }
+    for (const Step &st : sc.steps) if (!check_tile_table(sc, st)) return -21;
+    return 0;
+}
+
+// steps [step0, step1) of that schedule on (Lx, Dinv); Dinv holds dinv_end + 1 entries and is kept
+int emu_top_run(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                const int64_t *Ls, int64_t ssize, int64_t xsize, const int8_t *top_mask, int rank, int world,
+                int64_t dinv_base, int64_t step0, int64_t step1, double *Lx, double *Dinv_io,
+                int64_t *first_bad, int64_t *info_out)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    DistTop dt; dt.rank = rank; dt.world = world;
+    Schedule sc; build_schedule(S, nsuper, 0, sc, top_mask, dinv_base, &dt);
+    std::vector<double> Dinv(Dinv_io, Dinv_io + sc.dinv_size + 1);
+    std::vector<int> info;
+    run(S, sc, 0, nullptr, nullptr, nullptr, 0.0, Lx, Dinv, info, nullptr, false, step0, step1, true);
+    std::copy(Dinv.begin(), Dinv.begin() + sc.dinv_size, Dinv_io);
+    if (info[nsuper + 1] != 0) return -10;
+    *first_bad = -1; *info_out = 0;
+    for (int64_t s = 0; s < nsuper; s++) if (info[s]) { *first_bad = s; *info_out = info[s]; break; }
+    return 0;
+}
+
+int64_t emu_dinv_size_masked(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                             const int64_t *Ls, int64_t ssize, int64_t xsize, const int8_t *mask)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc, mask);
+    return sc.dinv_size;
 }
 
 int64_t emu_dinv_size(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,

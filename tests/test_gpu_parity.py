@@ -280,6 +280,87 @@ def test_multigpu_phases_simulated_on_one_gpu(engine, world):
         assert relerr(X.cpu().numpy(), want) < 1e-10
 
 
+@pytest.mark.parametrize("world,ob,ob2,size", [(2, 64, 128, 16), (4, 64, 64, 16), (3, 256, 1024, 24)])
+def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size):
+    """owner-computes top (mi355_factor_set_top_distribution / _top_plan / _top_run) with `world` handles on
+    one GPU; the broadcasts and the sums are done by hand on the device views RCCL would use"""
+    import torch
+    from oracle import port
+    from suitesparse_amd import multigpu
+    from test_multigpu import problem
+    g = problem("lap3d", size)
+    n = g["n"]
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    engine.set_tuning(2, ob); engine.set_tuning(7, ob2)
+    try:
+        runs = []
+        for r in range(world):
+            L = engine.SupernodalFactor(g)
+            L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+            runs.append(multigpu.PartitionedFactor(L, g, r, world, allreduce=lambda t: None, distribute_top=True,
+                                                   min_subtrees_per_rank=1))
+        assert all(rn.dist for rn in runs)
+        plan = runs[0].plan
+        for rn in runs[1:]:
+            assert (rn.plan[:, 1:] == plan[:, 1:]).all()
+        if ob2 <= 128:
+            assert len(set(int(r) for r in plan[:, 3])) > 1
+        for rn in runs:
+            assert rn.f.numeric_phase(0) == (-1, 0)
+        torch.cuda.synchronize()
+        for k in range(len(runs[0].tensors)):
+            tot = sum(rn.tensors[k] for rn in runs)
+            for rn in runs:
+                rn.tensors[k].copy_(tot)
+        torch.cuda.synchronize()
+        for k in range(len(plan)):
+            for rn in runs:
+                rn.f.top_run(k)
+            root = int(plan[k, 3])
+            for rn in runs:
+                if rn.rank != root:
+                    rn.bviews[k].copy_(runs[root].bviews[k])
+            torch.cuda.synchronize()
+        for rn in runs:
+            assert rn.f.top_run(len(plan)) == (-1, 0)
+        if runs[0].dinv_views:
+            tot = sum(rn.dinv_views[0] for rn in runs)
+            for rn in runs:
+                rn.dinv_views[0].copy_(tot)
+            torch.cuda.synchronize()
+        owner = runs[0].part["owner"]
+        for r, rn in enumerate(runs):
+            Lx = rn.f.Lx()
+            for s in range(g["nsuper"]):
+                if owner[s] in (r, -1):
+                    a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                    assert relerr(Lx[a:b], Lo[a:b]) < TOL_L, (r, s)
+        B = np.random.default_rng(2).standard_normal((3, n))
+        want = port.super_solve(g, Lo, port.super_solve(g, Lo, B.T.copy(), lower=True), lower=False).T
+        Xs = [torch.from_numpy(B.copy()).cuda() for _ in range(world)]
+
+        def summed():
+            torch.cuda.synchronize()
+            tot = sum(Xs)
+            for x in Xs:
+                x.copy_(tot)
+            torch.cuda.synchronize()
+        for rn, x in zip(runs, Xs):
+            rn.f.keep_rows_dev(x.data_ptr(), 3, n)
+            rn.f.solve_phase_dev(0, True, x.data_ptr(), 3, n)
+        summed()
+        for rn, x in zip(runs, Xs):
+            rn.f.solve_phase_dev(1, True, x.data_ptr(), 3, n)
+            rn.f.solve_phase_dev(1, False, x.data_ptr(), 3, n)
+            rn.f.solve_phase_dev(0, False, x.data_ptr(), 3, n)
+            rn.f.keep_rows_dev(x.data_ptr(), 3, n)
+        summed()
+        for x in Xs:
+            assert relerr(x.cpu().numpy(), want) < 1e-10
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+
+
 def test_zomplex_input_gives_complex_factor(engine):
     """A zomplex (split re/im), L complex: the zd_ instantiation (worker :69-83)"""
     g = load_golden("tcov_z30lo")

@@ -31,6 +31,12 @@ class EmuFactor:
                                            C.c_int64, f64p, f64p, C.c_int64, C.c_void_p, C.c_int64, i8p, C.c_int64]
         self.E.emu_dinv_size.restype = C.c_int64
         self.E.emu_dinv_size.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64]
+        self.E.emu_top_plan.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i8p,
+                                        C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self.E.emu_top_run.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i8p,
+                                       C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, f64p, f64p,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         self.Lx = np.zeros(g["xsize"])
         self.Dinv = np.zeros(self.E.emu_dinv_size(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"],
                                                   g["ssize"], g["xsize"]) + 1)
@@ -51,6 +57,47 @@ class EmuFactor:
         if phase == 0:
             self.dinv_local_end = int(end.value)
         return int(bad.value), int(info.value)
+
+    def set_top_distribution(self, rank, world):
+        g = self.g
+        self.rank, self.world = rank, world
+        # the Dinv slots of the own subtrees end where phase 0's schedule ends: known before phase 0 runs
+        loc = np.ascontiguousarray(self.local)
+        self.E.emu_dinv_size_masked.restype = C.c_int64
+        self.E.emu_dinv_size_masked.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i8p]
+        self.dinv_local_end = int(self.E.emu_dinv_size_masked(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"],
+                                                              g["Ls"], g["ssize"], g["xsize"], loc))
+        plan = np.zeros((4096, 4), dtype=np.int64)
+        cnt, nsteps, dend = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = self.E.emu_top_plan(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"],
+                                 self.top, rank, world, self.dinv_local_end, 4096, plan.reshape(-1), C.byref(cnt),
+                                 C.byref(nsteps), C.byref(dend))
+        assert rc == 0, rc
+        self.plan, self.nsteps = plan[:cnt.value].copy(), int(nsteps.value)
+        self.first_fail = (-1, 0)
+        return self.plan, (self.dinv_local_end, int(dend.value))
+
+    def top_run(self, seg):
+        g = self.g
+        nb = len(self.plan)
+        if seg == 0:
+            self.first_fail = (-1, 0)
+            self.Dinv[self.dinv_local_end:] = 0.0
+        step0 = 0 if seg == 0 else int(self.plan[seg - 1, 0])
+        step1 = self.nsteps if seg == nb else int(self.plan[seg, 0])
+        bad, info = C.c_int64(-1), C.c_int64(0)
+        rc = self.E.emu_top_run(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"],
+                                self.top, self.rank, self.world, self.dinv_local_end, step0, step1, self.Lx, self.Dinv,
+                                C.byref(bad), C.byref(info))
+        assert rc == 0, rc
+        if bad.value >= 0 and (self.first_fail[0] < 0 or bad.value < self.first_fail[0]):
+            self.first_fail = (int(bad.value), int(info.value))
+        return self.first_fail if seg == nb else (-1, 0)
+
+    def dinv_tensors(self, ranges):
+        import torch
+        t = torch.from_numpy(self.Dinv)
+        return [t[lo:hi] for lo, hi in ranges]
 
     def solve_phase_dev(self, part, lower, X_ptr, nrhs, d):
         g = self.g
@@ -141,6 +188,93 @@ def test_phases_with_simulated_ranks_match_oracle(kind, size, world):
                 assert relerr(f.Lx[a:b], Lo[a:b]) < 1e-11, (r, s)
 
 
+def run_distributed_lockstep(runners, facs):
+    """the owner-computes top with simulated ranks: every rank runs segment k, then block k travels"""
+    plans = [rn.plan for rn in runners]
+    for pl in plans[1:]:                                  # same broadcasts in the same order on every rank
+        assert pl.shape == plans[0].shape and (pl[:, 1:] == plans[0][:, 1:]).all()
+    for k in range(len(plans[0])):
+        for rn in runners:
+            rn.f.top_run(k)
+        root = int(plans[0][k, 3])
+        for rn in runners:
+            if rn.rank != root:
+                rn.bviews[k][...] = runners[root].bviews[k]
+    res = [rn.f.top_run(len(plans[0])) for rn in runners]
+    for rn in runners:                                    # block inverses: sum over the ranks
+        if rn.dinv_views:
+            tot = sum(r2.dinv_views[0].clone() for r2 in runners)
+            break
+    for rn in runners:
+        if rn.dinv_views:
+            rn.dinv_views[0][...] = tot
+    return res
+
+
+@pytest.mark.parametrize("kind,size,world,ob2", [("lap3d", 12, 2, 64), ("lap3d", 14, 4, 128), ("lap3d", 12, 3, 1024),
+                                                 ("lap2d", 40, 8, 64), ("elast", 5, 3, 64)])
+def test_distributed_top_with_simulated_ranks(kind, size, world, ob2):
+    """owner-computes top: every rank ends with the oracle's factor in its own subtrees and in the whole top,
+    and the solves on the partitioned factor work from the summed block inverses"""
+    import torch
+    from oracle import port
+    g = problem(kind, size)
+    n = g["n"]
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    emu = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    emu.emu_set_tuning(2, min(64, ob2)); emu.emu_set_tuning(7, ob2)      # small outer blocks: many owners
+    try:
+        facs = [EmuFactor(g) for _ in range(world)]
+        runners = [multigpu.PartitionedFactor(f, g, r, world, allreduce=lambda t: None, distribute_top=True,
+                                              min_subtrees_per_rank=1) for r, f in enumerate(facs)]
+        assert all(rn.dist for rn in runners)
+        roots = set(int(r) for r in runners[0].plan[:, 3])
+        if ob2 <= 128:
+            assert len(roots) > 1                           # the top really is spread over ranks
+        for rn in runners:
+            assert rn.f.numeric_phase(0) == (-1, 0)
+        for lo, hi in runners[0].part["top_ranges"]:
+            tot = sum(f.Lx[lo:hi] for f in facs)
+            for f in facs:
+                f.Lx[lo:hi] = tot
+        res = run_distributed_lockstep(runners, facs)
+        assert all(r == (-1, 0) for r in res)
+        owner = runners[0].part["owner"]
+        Lpx = g["Lpx"]
+        for r, f in enumerate(facs):
+            for s in range(g["nsuper"]):
+                if owner[s] == r or owner[s] == -1:
+                    a, b = int(Lpx[s]), int(Lpx[s + 1])
+                    nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                    got, want = f.Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                    low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T   # entries on or below the diagonal
+                    assert relerr(got[low], want[low]) < 1e-11, (r, s)
+        # solves
+        B = np.random.default_rng(1).standard_normal((2, n))
+        want_l = port.super_solve(g, Lo, B.T.copy(), lower=True).T
+        want = port.super_solve(g, Lo, want_l.T.copy(), lower=False).T
+        Xs = [torch.from_numpy(B.copy()) for _ in range(world)]
+
+        def summed():
+            tot = sum(x.numpy() for x in Xs)
+            for x in Xs:
+                x.numpy()[...] = tot
+        for rn, x in zip(runners, Xs):
+            rn.f.keep_rows_dev(x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(0, True, x.data_ptr(), 2, n)
+        summed()
+        for rn, x in zip(runners, Xs):
+            rn.f.solve_phase_dev(1, True, x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(1, False, x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(0, False, x.data_ptr(), 2, n)
+            rn.f.keep_rows_dev(x.data_ptr(), 2, n)
+        summed()
+        for x in Xs:
+            assert relerr(x.numpy(), want) < 1e-11
+    finally:
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024)
+
+
 @pytest.mark.parametrize("kind,size,world,nrhs", [("lap3d", 12, 2, 1), ("lap3d", 12, 4, 3), ("lap2d", 40, 8, 2)])
 def test_solve_phases_with_simulated_ranks(kind, size, world, nrhs):
     """lsolve / ltsolve on the partitioned factor: local sweeps + sum over the ranks + replicated top
@@ -204,7 +338,9 @@ from suitesparse_amd import multigpu
 from oracle import port
 g = tm.problem("lap3d", 10)
 f = tm.EmuFactor(g)
-run = multigpu.PartitionedFactor(f, g, rank, world)
+f.E.emu_set_tuning(2, 64); f.E.emu_set_tuning(7, 64)     # 64-column outer blocks: the top spreads over both ranks
+run = multigpu.PartitionedFactor(f, g, rank, world, min_subtrees_per_rank=1)
+assert run.dist and len(set(int(r) for r in run.plan[:, 3])) == 2
 st = run.numeric()
 so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
 owner = run.part["owner"]
