@@ -73,6 +73,13 @@ struct DeviceSchedule {
     DevBuf<PotrfTask> potrf;
     DevBuf<int32_t> relmap, solve_tmap;
     DevBuf<Schedule::TileEntry> gemm_tmap;
+    // grouped solve sweep (built on first use)
+    SolveSchedule ssched;
+    DevBuf<SolveGroupTask> sgroups;
+    DevBuf<PotrfTask> sutasks;
+    DevBuf<int32_t> stmap;
+    DevBuf<SolveRange> sranges;
+    bool solve_groups_ready = false;
 };
 
 }  // namespace
@@ -737,6 +744,59 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     const int64_t dcol = d;
     const bool mma = nr >= tuning().solve_mma_min;
     const int nrr = nr * F->E;                          // real columns of the row-major image
+    if (!cplx && !mma && nr <= SOLVE_NR && tuning().solve_group) {
+        // few right-hand sides: the sweep is a chain of dependent launches -- two per SOLVE_GROUP blocks
+        if (!DS.solve_groups_ready) {
+            build_solve_groups(DS.sched, DS.ssched);
+            HIP_TRY(DS.sgroups.upload(DS.ssched.groups.data(), DS.ssched.groups.size(), F->stream));
+            HIP_TRY(DS.sutasks.upload(DS.ssched.utasks.data(), DS.ssched.utasks.size(), F->stream));
+            HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));
+            HIP_TRY(DS.sranges.upload(DS.ssched.ranges.data(), DS.ssched.ranges.size(), F->stream));
+            DS.solve_groups_ready = true;
+        }
+        const std::vector<SolveStep> &gs = DS.ssched.steps;
+        for (size_t ii = 0; ii < gs.size(); ii++) {
+            const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
+            if (st.gcount <= 0) continue;
+            if (st.gcount > 0x7fffffffLL || st.stiles > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve tiles in one step");
+            auto group_kernel = [&]() {
+                const dim3 g((unsigned)st.gcount), b(256);
+                const SolveGroupTask *gp = DS.sgroups.p + st.gfirst;
+#define MI355_SG(T, NRT, MB) hipLaunchKernelGGL((k_solve_group<T, NRT, MB>), g, b, 0, F->stream, gp, F->Dinv.p, F->Lx.p, X, d, nr)
+#define MI355_SG_MB(T, NRT) do { if (st.maxblk <= 1) MI355_SG(T, NRT, 1); else if (st.maxblk <= 2) MI355_SG(T, NRT, 2); \
+                                 else MI355_SG(T, NRT, SOLVE_GROUP); } while (0)
+                if (lower) { if (nr == 1) MI355_SG_MB(false, 1); else MI355_SG_MB(false, SOLVE_NR); }
+                else       { if (nr == 1) MI355_SG_MB(true, 1); else MI355_SG_MB(true, SOLVE_NR); }
+#undef MI355_SG_MB
+#undef MI355_SG
+            };
+            if (lower) {
+                group_kernel();
+                if (st.stiles > 0)
+                    hipLaunchKernelGGL(k_solve_fwd_update, dim3((unsigned)st.stiles), dim3(256), 0, F->stream,
+                                       DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, F->Lx.p, F->dLs.p, X, d, nr);
+            } else {
+                if (st.rcount > 0) {
+                    if (st.rcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
+                    if (nr == 1)
+                        hipLaunchKernelGGL(k_solve_bwd_range<1>, dim3((unsigned)st.rcount), dim3(256), 0, F->stream,
+                                           DS.sutasks.p + st.ufirst, DS.sranges.p + st.rfirst, F->Lx.p, F->dLs.p, X, d, nr);
+                    else
+                        hipLaunchKernelGGL(k_solve_bwd_range<SOLVE_NR>, dim3((unsigned)st.rcount), dim3(256), 0, F->stream,
+                                           DS.sutasks.p + st.ufirst, DS.sranges.p + st.rfirst, F->Lx.p, F->dLs.p, X, d, nr);
+                }
+                group_kernel();
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(e1, F->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float gms = 0;
+        HIP_TRY(hipEventElapsedTime(&gms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        F->st_solve = gms;
+        return MI355_OK;
+    }
     if (mma) {
         const int64_t ldr = ((int64_t)nrr + 15) & ~(int64_t)15;
         const size_t need = (size_t)S.n * (size_t)ldr;
@@ -1126,6 +1186,8 @@ int mi355_set_tuning(int key, int value)
     else if (key == 7) tuning().ob2 = value;
     else if (key == 8) tuning().ob3 = value;
     else if (key == 9) tuning().solve_mma_min = value;
+    else if (key == 10) tuning().solve_group = value;
+    else if (key == 11) tuning().solve_bwd_div = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -319,6 +319,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
             pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
             pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
+            pt.urow0 = (int32_t)(j + nb); pt.pad = 0;
             const bool own = !dist || owner(s, j / WB) == dist->rank;
             L[lev].potrf[it].push_back(pt);
             L[lev].mine[it].push_back(own ? 1 : 0);
@@ -471,6 +472,95 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             flush_gemm(out, ls.trail[it], lev, S);
         }
         flush_gemm(out, ls.updates, lev, S);
+    }
+}
+
+void build_solve_groups(const Schedule &sc, SolveSchedule &out)
+{
+    out = SolveSchedule();
+    // the POTRF steps of one level are its iterations it = 0, 1, 2, ... in order; iteration it holds the
+    // block at columns [NB*it, NB*it + nb) of every supernode of the level that is that wide
+    size_t i = 0;
+    const size_t nst = sc.steps.size();
+    while (i < nst) {
+        if (sc.steps[i].kind != STEP_POTRF) { i++; continue; }
+        const int32_t lev = sc.steps[i].level;
+        std::vector<const Step *> its;
+        while (i < nst && sc.steps[i].level == lev) {
+            if (sc.steps[i].kind == STEP_POTRF) its.push_back(&sc.steps[i]);
+            i++;
+        }
+        for (size_t g0 = 0; g0 < its.size(); g0 += SOLVE_GROUP) {
+            SolveStep st;
+            st.gfirst = (int64_t)out.groups.size(); st.gcount = 0;
+            st.ufirst = (int64_t)out.utasks.size(); st.ucount = 0;
+            st.stiles = 0; st.tmap_off = (int64_t)out.tile_task.size();
+            st.maxblk = 1; st.pad = 0;
+            // groups: one per supernode present at the first iteration of the range
+            std::vector<std::pair<int32_t, int64_t>> by_s;         // (supernode, group index), sorted by supernode
+            const Step &f = *its[g0];
+            for (int64_t ti = f.first; ti < f.first + f.count; ti++) {
+                const PotrfTask &pt = sc.potrf[(size_t)ti];
+                SolveGroupTask gt;
+                gt.a_off = pt.a_off;
+                for (int b = 0; b < SOLVE_GROUP; b++) gt.dinv_off[b] = 0;
+                gt.dinv_off[0] = pt.dinv_off;
+                gt.lda = pt.lda;
+                gt.ncols = std::min<int32_t>(SOLVE_GROUP * NB, pt.nscol - pt.col0);
+                gt.x0 = pt.k1 + pt.col0;
+                gt.pad = 0;
+                st.maxblk = std::max<int32_t>(st.maxblk, (gt.ncols + NB - 1) / NB);
+                by_s.push_back({pt.s, (int64_t)out.groups.size()});
+                out.groups.push_back(gt);
+                st.gcount++;
+            }
+            std::sort(by_s.begin(), by_s.end());
+            // update tasks, group-major: collect the blocks of each group over the iterations of the range
+            std::vector<std::vector<PotrfTask>> blocks((size_t)st.gcount);
+            for (size_t b = 0; b < (size_t)SOLVE_GROUP && g0 + b < its.size(); b++) {
+                const Step &sb = *its[g0 + b];
+                for (int64_t ti = sb.first; ti < sb.first + sb.count; ti++) {
+                    const PotrfTask &pt = sc.potrf[(size_t)ti];
+                    auto itp = std::lower_bound(by_s.begin(), by_s.end(), std::make_pair(pt.s, (int64_t)-1));
+                    const int64_t gi = itp->second;
+                    out.groups[(size_t)gi].dinv_off[b] = pt.dinv_off;
+                    blocks[(size_t)(gi - st.gfirst)].push_back(pt);
+                }
+            }
+            for (int64_t gi = 0; gi < st.gcount; gi++) {
+                const SolveGroupTask &gt = out.groups[(size_t)(st.gfirst + gi)];
+                for (PotrfTask pt : blocks[(size_t)gi]) {
+                    const int32_t gcol0 = gt.x0 - pt.k1;            // first column of the group inside s
+                    pt.urow0 = gcol0 + gt.ncols;
+                    // several blocks of s update the same rows of s in one launch: nscol = 0 makes the update
+                    // kernels treat every row as shared (atomic adds, row index from Ls)
+                    pt.nscol = 0;
+                    const int64_t below = (int64_t)pt.lda - pt.urow0;
+                    if (below <= 0) continue;
+                    const int64_t nt = (below + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                    pt.stile0 = st.stiles;
+                    st.stiles += nt;
+                    out.tile_task.insert(out.tile_task.end(), (size_t)nt, (int32_t)st.ucount);
+                    out.utasks.push_back(pt);
+                    st.ucount++;
+                }
+            }
+            // backward sweep: runs of at most `run` tiles, long enough to amortise the flush (a transpose-reduce
+            // and 64 atomics into entries every run of the block hits) and short enough to leave ~512 runs
+            st.rfirst = (int64_t)out.ranges.size();
+            const int64_t run = std::min<int64_t>(32, std::max<int64_t>(2, st.stiles / std::max(1, tuning().solve_bwd_div)));
+            for (int64_t u = 0; u < st.ucount; u++) {
+                const PotrfTask &pt = out.utasks[(size_t)(st.ufirst + u)];
+                const int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                for (int64_t t0 = 0; t0 < nt; t0 += run) {
+                    SolveRange r;
+                    r.task = (int32_t)u; r.tile0 = (int32_t)t0; r.ntiles = (int32_t)std::min<int64_t>(run, nt - t0); r.pad = 0;
+                    out.ranges.push_back(r);
+                }
+            }
+            st.rcount = (int64_t)out.ranges.size() - st.rfirst;
+            out.steps.push_back(st);
+        }
     }
 }
 

@@ -57,6 +57,37 @@ struct PotrfTask {
     int32_t col0;       // first column of the block inside s (info = col0 + j + 1)
     int32_t k1;         // Super[s]
     int32_t nscol;      // columns of s
+    int32_t urow0;      // first row (inside s) of the solve row tiles: col0 + nb, or the end of the solve group
+    int32_t pad;
+};
+
+// Solve groups (real factor, few right-hand sides): SOLVE_GROUP consecutive 64-column blocks of a supernode are
+// swept by ONE workgroup (their diagonal solves and the updates among them), and the rows below the group get
+// the updates of all its blocks in ONE launch -- two launches per 256 columns instead of eight; the sweep
+// is a chain of dependent launches, so its length is what the solve time is made of.
+constexpr int SOLVE_GROUP = 4;
+struct SolveGroupTask {
+    int64_t a_off;                      // L[col0][col0] of the group's first block
+    int64_t dinv_off[SOLVE_GROUP];      // block inverses (ld = block width)
+    int32_t lda;                        // = nsrow
+    int32_t ncols;                      // columns of the group; blocks of NB, the last may be narrower
+    int32_t x0;                         // first row of X the group owns (Super[s] + col0)
+    int32_t pad;
+};
+struct SolveRange { int32_t task, tile0, ntiles, pad; };   // a run of row tiles of one update task (backward sweep)
+struct SolveStep {
+    int64_t gfirst, gcount;             // group tasks
+    int64_t ufirst, ucount;             // per-block update tasks (PotrfTask with urow0 = end of the group)
+    int64_t stiles, tmap_off;           // their row tiles
+    int32_t maxblk, pad;                // most 64-column blocks of any group of the step
+    int64_t rfirst, rcount;             // runs of row tiles for the backward sweep
+};
+struct SolveSchedule {
+    std::vector<SolveGroupTask> groups;
+    std::vector<PotrfTask> utasks;
+    std::vector<int32_t> tile_task;
+    std::vector<SolveRange> ranges;
+    std::vector<SolveStep> steps;       // forward order
 };
 
 // one (descendant d -> ancestor s) update, the unit of a3.4 in SURVEY.md section 8
@@ -149,8 +180,12 @@ std::string validate_symbolic(const Symbolic &S);
 void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Schedule &out,
                     const int8_t *mask = nullptr, int64_t dinv_base = 0, const DistTop *dist = nullptr);
 
+// the grouped solve sweep over the POTRF steps of sc (any schedule: full, or one part of a partition)
+struct Schedule;
+void build_solve_groups(const Schedule &sc, SolveSchedule &out);
+
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; int solve_group = 1; int solve_bwd_div = 256; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_solve_fwd_update(
     const PotrfTask t = tasks[tile_task[blockIdx.x]];
     const int tid = threadIdx.x, nb = t.nb;
     const int rl = tid & 63, w = tid >> 6;
-    const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + rl;     // row inside s
+    const int r = t.urow0 + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + rl;         // row inside s
     const bool ok = r < t.lda;
     const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);     // L[r][col0]
     const double *__restrict__ x1 = X + t.k1 + t.col0;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
         const PotrfTask t = tasks[tile_task[blockIdx.x]];
         const int nb = t.nb;
         if (w * 16 >= nb) return;                       // no barrier in this kernel
-        const int r = t.col0 + nb + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + lane;
+        const int r = t.urow0 + (int)(blockIdx.x - t.stile0) * SOLVE_ROWS + lane;
         const bool ok = r < t.lda;
         const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
         double *__restrict__ x1 = X + t.k1 + t.col0;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
             }
             const int nb = t.nb;
             if (w * 16 >= nb) continue;                 // wave-uniform
-            const int r = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + lane;
+            const int r = t.urow0 + (int)(e - t.stile0) * SOLVE_ROWS + lane;
             const bool ok = r < t.lda;
             const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
             int64_t row = 0;
@@ -250,6 +250,191 @@ __global__ __launch_bounds__(256) void k_solve_bwd_update(
             }
         }
         if (cur >= 0) flush();
+    }
+}
+
+// backward update over a work list: entry = a run of consecutive row tiles of ONE block task (the host cuts
+// the tall blocks into runs, schedule.cpp), summed in registers and flushed once -- one transpose-reduce and
+// one set of atomics per run.  Two tiles are in flight per pass (32 loads of L per lane), so a run costs
+// about half a memory latency per tile instead of a whole one.
+constexpr int BR_U = 2;     // row tiles in flight per pass of k_solve_bwd_range
+template <int NRA>
+__global__ __launch_bounds__(256) void k_solve_bwd_range(
+    const PotrfTask *__restrict__ tasks, const SolveRange *__restrict__ work,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ X, int64_t ldx, int nrhs)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const SolveRange e = work[blockIdx.x];
+    const PotrfTask t = tasks[e.task];
+    const int nb = t.nb;
+    if (w * 16 >= nb) return;                           // no barrier in this kernel
+    double acc[NRA][16];
+#pragma unroll
+    for (int j = 0; j < NRA; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[j][q] = 0.0;
+    for (int tt = 0; tt < e.ntiles; tt += BR_U) {
+        double l[BR_U][16], xr[BR_U][NRA];
+#pragma unroll
+        for (int u = 0; u < BR_U; u++) {
+            const int r = t.urow0 + (e.tile0 + tt + u) * SOLVE_ROWS + lane;
+            const bool ok = (tt + u < e.ntiles) && r < t.lda;
+            const double *__restrict__ Lr = Lx + t.a_off + ((ok ? r : t.col0) - t.col0);
+            int64_t row = 0;
+            if (ok) row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+#pragma unroll
+            for (int j = 0; j < NRA; j++) xr[u][j] = (ok && j < nrhs) ? X[row + (int64_t)j * ldx] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int c = w * 16 + q;
+                l[u][q] = (ok && c < nb) ? Lr[(int64_t)(c < nb ? c : 0) * t.lda] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BR_U; u++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+#pragma unroll
+                for (int j = 0; j < NRA; j++) acc[j][q] += l[u][q] * xr[u][j];
+    }
+    double *__restrict__ x1 = X + t.k1 + t.col0;
+#pragma unroll
+    for (int j = 0; j < NRA; j++) {
+        if (j >= nrhs) break;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (w * 16 + half * 8 >= nb) break;
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = acc[j][half * 8 + q];
+            const double s = wave_colsum8(v, lane);
+            const int c = w * 16 + half * 8 + lane;
+            if (lane < 8 && c < nb) atomic_add_f64(x1 + c + (int64_t)j * ldx, -s);
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_solve_group: the part of a sweep that lies inside one solve group (SOLVE_GROUP consecutive 64-column
+// blocks of a supernode, schedule.hpp): the diagonal solves x_c <- inv(L_cc) x_c and the updates between the
+// group's blocks, one workgroup per group, x of the group in LDS.  The work is a chain of small mat-vecs,
+// step s = c(c+1)/2 + b  <->  block (c, b), b <= c < nblk:
+//   forward  (s ascending) : (c,b), b < c:  x_c -= L(c,b)   x_b ;   (c,c):  x_c <- inv(L_cc)   x_c
+//   backward (s descending): (c,c):  x_c <- inv(L_cc)^T x_c ;   (c,b), b < c:  x_b -= L(c,b)^T x_c
+// each at most 64 x 64, 16 entries per thread, lanes along the rows of the block; forward the column range is
+// split over the 4 waves and reduced through LDS, backward every wave owns 16 columns and the sums over the
+// rows go through LDS as 16 partial sums per column.  A step computes in a fraction of a memory latency, so ALL entries of ALL
+// steps are loaded into registers before the first step (MAXBLK(MAXBLK+1)/2 x 16 doubles per thread): the
+// chain pays one memory latency, not one per step (18 -> 9 us per group of four).  MAXBLK = most blocks of
+// any group in the launch (1, 2 or SOLVE_GROUP): the wide leaf levels keep a small register footprint.
+//------------------------------------------------------------------------------
+__host__ __device__ constexpr int sg_c(int s) { return s >= 6 ? 3 : s >= 3 ? 2 : s >= 1 ? 1 : 0; }
+__host__ __device__ constexpr int sg_b(int s) { return s - sg_c(s) * (sg_c(s) + 1) / 2; }
+static_assert(SOLVE_GROUP == 4, "sg_c/sg_b enumerate the blocks of a group of four");
+
+template <bool TRANS, int NR, int MAXBLK>
+__global__ __launch_bounds__(256) void k_solve_group(
+    const SolveGroupTask *__restrict__ groups, const double *__restrict__ Dinv, const double *__restrict__ Lx,
+    double *__restrict__ X, int64_t ldx, int nrhs)
+{
+    constexpr int NS = MAXBLK * (MAXBLK + 1) / 2;
+    __shared__ double xs[MAXBLK * NB][NR];
+    __shared__ double red[TRANS ? 1 : 4][NB][NR];
+    __shared__ double redT[TRANS ? NB : 1][17][NR];
+    const SolveGroupTask t = groups[blockIdx.x];
+    const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
+    const int ncols = t.ncols, nblk = (ncols + NB - 1) / NB;
+    double *__restrict__ x0 = X + t.x0;
+    // entries of block (c, b) for this thread; everything outside the block (and the strict upper part of an
+    // inverse) reads as zero
+    // forward: entries (row i, columns part + 4q) of block (c, b); backward: wave `part` owns columns
+    // [16 part, 16 part + 16) and holds entries (row 16 rc + lane%16, column 16 part + 4 cc + lane/16) at
+    // [4 cc + rc] -- either way the lanes run along the rows (coalesced; column-strided lanes took 64 cache
+    // lines per load instruction and 17 us per group)
+    const int r16 = i & 15, c4 = i >> 4;
+    auto load = [&](int b, int c, double (&m)[16]) {
+        const int nbb = min(NB, ncols - NB * b), nbc = min(NB, ncols - NB * c);
+        const double *__restrict__ D = Dinv + t.dinv_off[b];
+        const double *__restrict__ Lb = Lx + t.a_off + (int64_t)NB * c + (int64_t)NB * b * t.lda;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = TRANS ? 16 * (q & 3) + r16 : i;
+            const int col = TRANS ? 16 * part + 4 * (q >> 2) + c4 : part + 4 * q;
+            if (c == b) m[q] = (row < nbb && col <= row) ? D[row + col * nbb] : 0.0;
+            else        m[q] = (row < nbc && col < nbb) ? Lb[row + (int64_t)col * t.lda] : 0.0;
+        }
+    };
+    double m[NS][16];
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+        const int s = TRANS ? NS - 1 - u : u;                // in the order of use
+        if (sg_c(s) < nblk) load(sg_b(s), sg_c(s), m[s]);
+    }
+    for (int idx = tid; idx < MAXBLK * NB * NR; idx += 256) {
+        const int r = idx % (MAXBLK * NB), j = idx / (MAXBLK * NB);
+        xs[r][j] = (r < ncols && j < nrhs) ? x0[r + (int64_t)j * ldx] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+        const int s = TRANS ? NS - 1 - u : u;
+        const int b = sg_b(s), c = sg_c(s);
+        if (c >= nblk) continue;                              // uniform over the workgroup
+        if constexpr (TRANS) {
+            // y_col = sum_row M[row][col] x_c[row]: 16 partial sums per column (one per lane%16) through LDS.
+            // Target block: b (== c for the diagonal solve, which reads x_c before the first barrier and
+            // writes it after)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                double acc[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) acc[j] = 0.0;
+#pragma unroll
+                for (int rc = 0; rc < 4; rc++) {
+#pragma unroll
+                    for (int j = 0; j < NR; j++) acc[j] += m[s][4 * cc + rc] * xs[NB * c + 16 * rc + r16][j];
+                }
+#pragma unroll
+                for (int j = 0; j < NR; j++) redT[16 * part + 4 * cc + c4][r16][j] = acc[j];
+            }
+            __syncthreads();
+            if (tid < NB) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 16; p++) v += redT[tid][p][j];
+                    if (c == b) xs[NB * b + tid][j] = v; else xs[NB * b + tid][j] -= v;
+                }
+            }
+            __syncthreads();
+        } else {
+            const int src = b, dst = c;
+            double acc[NR];
+#pragma unroll
+            for (int j = 0; j < NR; j++) acc[j] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) acc[j] += m[s][q] * xs[NB * src + part + 4 * q][j];
+            }
+#pragma unroll
+            for (int j = 0; j < NR; j++) red[part][i][j] = acc[j];
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const double v = red[0][i][j] + red[1][i][j] + red[2][i][j] + red[3][i][j];
+                    if (c == b) xs[NB * dst + i][j] = v; else xs[NB * dst + i][j] -= v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < ncols * NR; idx += 256) {
+        const int r = idx % ncols, j = idx / ncols;
+        if (j < nrhs) x0[r + (int64_t)j * ldx] = xs[r][j];
     }
 }
 
