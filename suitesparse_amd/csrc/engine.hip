@@ -88,6 +88,8 @@ namespace { struct EventTimer; }
 struct mi355_factor_s {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;             // look-ahead: the far part of the outermost trailing updates (STEP_SIDE)
+    std::vector<hipEvent_t> side_ev;        // fork/join events, reused by every factorization
     int xtype = MI355_REAL;
     int E = 1;                  // doubles per entry: 1 real, 2 complex (interleaved)
     // host copy of the symbolic factor
@@ -168,18 +170,18 @@ struct EventTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];   // 0 gemm64 1 potrf 2 asm 3 gemm128
     bool on = false;
     hipStream_t st = nullptr;
-    void begin(int kind)
+    void begin(int kind, hipStream_t on_stream = nullptr)
     {
         if (!on) return;
         hipEvent_t x, y;
         (void)hipEventCreate(&x); (void)hipEventCreate(&y);
-        (void)hipEventRecord(x, st);
+        (void)hipEventRecord(x, on_stream ? on_stream : st);
         ev[kind].push_back({x, y});
     }
-    void end(int kind)
+    void end(int kind, hipStream_t on_stream = nullptr)
     {
         if (!on) return;
-        (void)hipEventRecord(ev[kind].back().second, st);
+        (void)hipEventRecord(ev[kind].back().second, on_stream ? on_stream : st);
     }
     bool pending = false;
     void drop()
@@ -231,10 +233,27 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     if (steplog) { (void)hipEventCreate(&le0); (void)hipEventCreate(&le1); }
     struct LogCloser { FILE *&f; hipEvent_t &a, &b; ~LogCloser() { if (f) { fclose(f); (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } } closer{steplog, le0, le1};
     if (step1 < 0) step1 = (int64_t)D.sched.steps.size();
+    bool side_pending = false;
     for (int64_t si = step0; si < step1; si++) {
         const Step &st = D.sched.steps[(size_t)si];
         if (st.count <= 0) continue;
-        if (steplog) (void)hipEventRecord(le0, F->stream);
+        // look-ahead fork/join (schedule.hpp): `q` is the stream this step launches on
+        hipStream_t q = F->stream;
+        if ((st.flags & STEP_JOIN) && side_pending) {
+            HIP_TRY(hipStreamWaitEvent(F->stream, F->side_ev[1], 0));
+            side_pending = false;
+        }
+        if (st.flags & STEP_SIDE) {
+            while (F->side_ev.size() < 2) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                F->side_ev.push_back(ev);
+            }
+            HIP_TRY(hipEventRecord(F->side_ev[0], F->stream));
+            HIP_TRY(hipStreamWaitEvent(F->side, F->side_ev[0], 0));
+            q = F->side;
+        }
+        if (steplog) (void)hipEventRecord(le0, q);
         if (st.kind == STEP_POTRF) {
             if (st.count > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many POTRF tasks in one step");
             tm.begin(1);
@@ -246,29 +265,33 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
             const int tk = st.big ? 3 : 0;
-            tm.begin(tk);
+            tm.begin(tk, q);
             if (st.big)
                 hipLaunchKernelGGL(cplx ? k_gemm128<true> : k_gemm128<false>, dim3((unsigned)st.ntiles),
-                                   dim3(256), 0, F->stream,
+                                   dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
                                    (unsigned long long *)nullptr);
             else if (cplx)
-                hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
             else if (st.trsm && !st.big)
-                hipLaunchKernelGGL(k_trsm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                hipLaunchKernelGGL(k_trsm64, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p);
             else
-                hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream,
+                hipLaunchKernelGGL(k_gemm64, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
-            tm.end(tk);
+            tm.end(tk, q);
             F->st_ngemm += 1;
             if (tk == 3) F->st_nbig += 1;
             F->st_tiles += (double)st.ntiles;
+            if (st.flags & STEP_SIDE) {
+                HIP_TRY(hipEventRecord(F->side_ev[1], F->side));
+                side_pending = true;
+            }
         }
         HIP_TRY(hipGetLastError());
         if (steplog) {
-            (void)hipEventRecord(le1, F->stream);
+            (void)hipEventRecord(le1, q);
             (void)hipEventSynchronize(le1);
             float ms = 0;
             (void)hipEventElapsedTime(&ms, le0, le1);
@@ -292,6 +315,7 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             }
         }
     }
+    if (side_pending) HIP_TRY(hipStreamWaitEvent(F->stream, F->side_ev[1], 0));
     return MI355_OK;
 }
 
@@ -343,7 +367,13 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     F->xtype = xtype;
     F->E = (xtype == MI355_COMPLEX) ? 2 : 1;
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+    {
+        // the panel chain (main stream) must get its few workgroups in while a trailing update fills the chip
+        int plo = 0, phi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        HIP_TRY(hipStreamCreateWithPriority(&F->stream, hipStreamNonBlocking, phi));
+        HIP_TRY(hipStreamCreateWithPriority(&F->side, hipStreamNonBlocking, plo));
+    }
 
     F->Super.assign(Super, Super + (nsuper > 0 ? nsuper + 1 : 0));
     F->Lpi.assign(Lpi, Lpi + (nsuper > 0 ? nsuper + 1 : 0));
@@ -382,7 +412,9 @@ int mi355_factor_free(mi355_factor *F)
 {
     if (!F) return MI355_OK;
     (void)hipSetDevice(F->device);
+    if (F->side) { (void)hipStreamSynchronize(F->side); (void)hipStreamDestroy(F->side); }
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
+    for (hipEvent_t ev : F->side_ev) (void)hipEventDestroy(ev);
     if (F->timer) { F->timer->drop(); delete F->timer; }
     delete F->part_local;
     delete F->part_top;
@@ -1188,6 +1220,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 9) tuning().solve_mma_min = value;
     else if (key == 10) tuning().solve_group = value;
     else if (key == 11) tuning().solve_bwd_div = std::max(1, value);
+    else if (key == 12) tuning().lookahead = value;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

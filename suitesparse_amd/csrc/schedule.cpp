@@ -73,6 +73,7 @@ struct LevelSteps {
     // per iteration it: tasks of all supernodes of this level
     std::vector<std::vector<PotrfTask>> potrf;
     std::vector<std::vector<GemmTask>> trsm, trail;
+    std::vector<std::vector<GemmTask>> rest;      // look-ahead: the far part of the outermost trailing updates
     std::vector<GemmTask> updates;
     // DistTop: is potrf[it][i] (and its trsm task) this rank's; blocks that complete at iteration it
     std::vector<std::vector<int8_t>> mine;
@@ -80,7 +81,7 @@ struct LevelSteps {
     void ensure(size_t it)
     {
         if (potrf.size() <= it) {
-            potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); mine.resize(it + 1); bcast.resize(it + 1);
+            potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); rest.resize(it + 1); mine.resize(it + 1); bcast.resize(it + 1);
         }
     }
 };
@@ -147,13 +148,14 @@ namespace {
 // append the GEMM tasks as up to two steps (big-tile tasks first, then small-tile tasks: the two
 // kernels of one step touch disjoint targets or use atomics, so their order is free); assigns the
 // tile0 prefix sums
-void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, const Symbolic &S, int32_t trsm = 0)
+void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, const Symbolic &S, int32_t trsm = 0,
+                int32_t flags = 0)
 {
     if (tasks.empty()) return;
     const Tuning &tu = tuning();
     for (int big = 1; big >= 0; big--) {
         Step st;
-        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm;
+        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm; st.flags = flags; st.pad = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
         st.tmap_off = (int64_t)out.gemm_tile_tab.size();
         std::vector<Schedule::TileEntry> seq;
@@ -361,6 +363,20 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     break;
                 }
                 if (!own) break;
+                if (!dist && tuning().lookahead && lvl > 0 && lvl + 1 == W.size() && e + W[lvl] < ncol_eff) {
+                    // look-ahead: columns [e, e1) = the next outer block, on the critical path; [e1, end) = the rest
+                    const int64_t e1 = e + W[lvl];
+                    L[lev].trail[it].push_back(make_gemm(
+                        psx + e + b0 * nsrow, psx + e + b0 * nsrow,
+                        psx + e + e * nsrow, -1, nsrow, nsrow, nsrow,
+                        below, e1 - e, K, GEMM_DIRECT_SUB));
+                    L[lev].rest[it].push_back(make_gemm(
+                        psx + e1 + b0 * nsrow, psx + e1 + b0 * nsrow,
+                        psx + e1 + e1 * nsrow, -1, nsrow, nsrow, nsrow,
+                        nsrow - e1, ncol_eff - e1, K, GEMM_DIRECT_SUB));
+                    out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
+                    break;
+                }
                 L[lev].trail[it].push_back(make_gemm(
                     psx + e + b0 * nsrow, psx + e + b0 * nsrow,
                     psx + e + e * nsrow, -1, nsrow, nsrow, nsrow,
@@ -456,7 +472,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 ti32++;
             }
             Step st;
-            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0;
+            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0; st.flags = 0; st.pad = 0;
             st.first = (int64_t)out.potrf.size();
             st.count = (int64_t)pts.size();
             st.ntiles = st.count;
@@ -469,9 +485,12 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 bp.step = (int64_t)out.steps.size();
                 out.bcasts.push_back(bp);
             }
-            flush_gemm(out, ls.trail[it], lev, S);
+            // an iteration that ends an outer block: its update of the next block waits for the previous far
+            // part (same target columns), its own far part then goes to the side stream
+            flush_gemm(out, ls.trail[it], lev, S, 0, ls.rest[it].empty() ? 0 : STEP_JOIN);
+            flush_gemm(out, ls.rest[it], lev, S, 0, STEP_SIDE);
         }
-        flush_gemm(out, ls.updates, lev, S);
+        flush_gemm(out, ls.updates, lev, S, 0, STEP_JOIN);
     }
 }
 

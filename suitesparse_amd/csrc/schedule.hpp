@@ -110,7 +110,16 @@ struct Step {
     int64_t ntiles;     // STEP_GEMM: total tiles (= grid size); STEP_POTRF: = count
     int64_t stiles;     // STEP_POTRF: row tiles (SOLVE_ROWS rows each) below the blocks, for the solves
     int64_t tmap_off;   // offset of this step's tile -> task table (gemm_tile_task / solve_tile_task)
+    int32_t flags;      // STEP_SIDE / STEP_JOIN
+    int32_t pad;
 };
+// Look-ahead: the part of an outermost trailing update that lies beyond the NEXT outer block does not feed the
+// next block's panel chain, so it runs on a second stream (STEP_SIDE) next to that chain; whatever touches its
+// targets or reads all of the supernode afterwards first waits for it (STEP_JOIN).  Off by default
+// (Tuning::lookahead): at 150^3 it shortens the factorization by 1.6 % only -- the panel-chain kernels wait
+// for workgroup slots behind the update's queued tiles and run twice as long, stream priorities
+// notwithstanding -- and the overlapped launches blur the per-kernel durations the roofline is built from.
+constexpr int32_t STEP_SIDE = 1, STEP_JOIN = 2;
 
 struct Symbolic {
     int64_t n = 0, nsuper = 0, ssize = 0, xsize = 0;
@@ -185,7 +194,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; int solve_group = 1; int solve_bwd_div = 256; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 12; int solve_group = 1; int solve_bwd_div = 256; int lookahead = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);
