@@ -72,10 +72,21 @@ def cpu_baseline(kind, grid):
             assert st == 0
             t = r.info()["t_factor"]
             best = t if best is None else min(best, t)
+        # the reference's supernodal solve (cholmod_l_super_lsolve + _ltsolve) on the same sample, nrhs = 1
+        import numpy as np
+        b = np.ones(p["n"], dtype=np.complex128 if np.iscomplexobj(p["Ax"]) else np.float64)
+        tsolve = None
+        for _ in range(2):
+            t0 = time.time()
+            y = r.super_solve(b, lower=True)
+            r.super_solve(y, lower=False)
+            dt = time.time() - t0
+            tsolve = dt if tsolve is None else min(tsolve, dt)
         return {"value": round(inf["fl"] / best * 1e-9, 2), "unit": "GFLOP/s", "cores": int(r.nthreads()),
-                "kind": "reference",
+                "kind": "reference", "solve_ms_nrhs1": round(tsolve * 1e3, 2),
                 "sample": f"{name}, same nested-dissection ordering, fl={inf['fl']:.4g}, "
-                          f"reference cholmod_l_super_numeric + MKL, best of 2 = {best:.3f} s"}
+                          f"reference cholmod_l_super_numeric + MKL, best of 2 = {best:.3f} s; "
+                          f"cholmod_l_super_lsolve + _ltsolve, nrhs 1, best of 2 = {tsolve * 1e3:.1f} ms"}
     except Exception as e:      # noqa: BLE001
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
 

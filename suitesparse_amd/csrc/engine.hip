@@ -752,6 +752,19 @@ int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64
 
 double *mi355_factor_device_Dinv(mi355_factor *F) { return F ? F->Dinv.p : nullptr; }
 
+// the grouped sweep's work lists (schedule.hpp: SolveSchedule) of one schedule, built and uploaded on first use
+static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
+{
+    if (DS.solve_groups_ready) return MI355_OK;
+    build_solve_groups(DS.sched, DS.ssched);
+    HIP_TRY(DS.sgroups.upload(DS.ssched.groups.data(), DS.ssched.groups.size(), F->stream));
+    HIP_TRY(DS.sutasks.upload(DS.ssched.utasks.data(), DS.ssched.utasks.size(), F->stream));
+    HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));
+    HIP_TRY(DS.sranges.upload(DS.ssched.ranges.data(), DS.ssched.ranges.size(), F->stream));
+    DS.solve_groups_ready = true;
+    return MI355_OK;
+}
+
 // part == nullptr: the whole factor; else the sweeps over one masked schedule of a partitioned factor
 static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr)
 {
@@ -778,14 +791,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     const int nrr = nr * F->E;                          // real columns of the row-major image
     if (!cplx && !mma && nr <= SOLVE_NR && tuning().solve_group) {
         // few right-hand sides: the sweep is a chain of dependent launches -- two per SOLVE_GROUP blocks
-        if (!DS.solve_groups_ready) {
-            build_solve_groups(DS.sched, DS.ssched);
-            HIP_TRY(DS.sgroups.upload(DS.ssched.groups.data(), DS.ssched.groups.size(), F->stream));
-            HIP_TRY(DS.sutasks.upload(DS.ssched.utasks.data(), DS.ssched.utasks.size(), F->stream));
-            HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));
-            HIP_TRY(DS.sranges.upload(DS.ssched.ranges.data(), DS.ssched.ranges.size(), F->stream));
-            DS.solve_groups_ready = true;
-        }
+        { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
         const std::vector<SolveStep> &gs = DS.ssched.steps;
         for (size_t ii = 0; ii < gs.size(); ii++) {
             const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
@@ -849,7 +855,45 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         X = F->Yrow.p;
         d = ldr;
     }
-    if (lower) {
+    if (mma && tuning().solve_group) {
+        // many right-hand sides, grouped: k_solve_group_mma per SOLVE_GROUP blocks + the MFMA updates of the rows below
+        { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
+        const std::vector<SolveStep> &gs = DS.ssched.steps;
+        for (size_t ii = 0; ii < gs.size(); ii++) {
+            const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
+            if (st.gcount <= 0) continue;
+            if (st.gcount > 0x7fffffffLL || st.stiles > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve tiles in one step");
+            auto group_kernel = [&]() {
+                const dim3 g((unsigned)st.gcount, (unsigned)((nrr + SG_CW - 1) / SG_CW)), b(256);
+                const SolveGroupTask *gp = DS.sgroups.p + st.gfirst;
+#define MI355_SGM(T, EE, MB) hipLaunchKernelGGL((k_solve_group_mma<T, EE, MB>), g, b, 0, F->stream, gp, F->Dinv.p, F->Lx.p, X, d, nrr)
+#define MI355_SGM_MB(T, EE) do { if (st.maxblk <= 1) MI355_SGM(T, EE, 1); else if (st.maxblk <= 2) MI355_SGM(T, EE, 2); \
+                                 else MI355_SGM(T, EE, SOLVE_GROUP); } while (0)
+                if (lower) { if (cplx) MI355_SGM_MB(false, 2); else MI355_SGM_MB(false, 1); }
+                else       { if (cplx) MI355_SGM_MB(true, 2); else MI355_SGM_MB(true, 1); }
+#undef MI355_SGM_MB
+#undef MI355_SGM
+            };
+            const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+            const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
+            if (lower) {
+                group_kernel();
+                if (st.stiles > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
+                                           DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
+            } else {
+                if (st.stiles > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma<2> : k_solve_bwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
+                                           DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, st.stiles, group,
+                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                group_kernel();
+            }
+            HIP_TRY(hipGetLastError());
+        }
+    } else if (lower) {
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
             if (st.kind != STEP_POTRF || st.count <= 0) continue;

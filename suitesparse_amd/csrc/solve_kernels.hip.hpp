@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
         }
         const int nb = t.nb;
         const int nq = (nb + 3) >> 2;                    // k-steps of 4 columns that hold anything
-        const int rbase = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS + w * 16;       // first row of this wave
+        const int rbase = t.urow0 + (int)(e - t.stile0) * SOLVE_ROWS + w * 16;       // first row of this wave
         const int r = rbase + l15;                       // operand row of this lane
         const int64_t roff = t.a_off + ((r < t.lda ? r : t.col0) - t.col0);
         double al[16], ai[E == 2 ? 16 : 1];
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
             t = tasks[ti];
         }
         const int nb = t.nb;
-        const int r0 = t.col0 + nb + (int)(e - t.stile0) * SOLVE_ROWS;
+        const int r0 = t.urow0 + (int)(e - t.stile0) * SOLVE_ROWS;
         const int rows_here = min(SOLVE_ROWS, t.lda - r0);
         const int nq = (rows_here + 3) >> 2;             // k-steps of 4 rows that hold anything (the rest is zero)
         const int r = r0 + lane;
@@ -739,6 +739,128 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
 #pragma unroll
                 for (int jb = 0; jb < 4; jb++)
                     if (i < nb && 16 * jb + l15 < nj) x1[(int64_t)i * ldr + j0 + 16 * jb + l15] = acc[jb][g];
+            }
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_solve_group_mma: k_solve_group for many right-hand sides (row-major image Y, 64 real columns per pass, the
+// group's rows of Y in LDS).  Same chain of steps (c, b); each step is a 64 x 64 x 64 product on the MFMA pipe:
+// the block of L (or the block inverse) is the A operand, read from global memory straight in operand layout
+// (wave w owns result rows [16w, 16w+16) of the target block), the source rows of Y the B operand from LDS.
+// The operands of the next NSETS steps are in flight in a ring of register sets (all ten steps for a real
+// factor, five for a complex one, whose steps take Re and Im of the block).  Complex: second product with
+// Im(block) against the pair-swapped image of Y, as in k_solve_fwd_mma / k_solve_bwd_mma.
+//------------------------------------------------------------------------------
+constexpr int SG_CW = 16;      // real columns of Y per workgroup of k_solve_group_mma
+template <bool TRANS, int E, int MAXBLK>
+__global__ __launch_bounds__(256) void k_solve_group_mma(
+    const SolveGroupTask *__restrict__ groups, const double *__restrict__ Dinv, const double *__restrict__ Lx,
+    double *__restrict__ Y, int64_t ldr, int nrhs)
+{
+    constexpr int NS = MAXBLK * (MAXBLK + 1) / 2;
+    constexpr int NSETS = (E == 1) ? (NS < 8 ? NS : 8) : (NS < 4 ? NS : 4);
+    __shared__ double Yg[MAXBLK * NB][SG_CW + 2];
+    const SolveGroupTask t = groups[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ncols = t.ncols, nblk = (ncols + NB - 1) / NB;
+    double *__restrict__ y0 = Y + (int64_t)t.x0 * ldr;
+    // A operand of step (c, b): A[i][k], i = 16w + lane%16, k = 4q + lane/16 -- entry (i, k) of the block, or
+    // the conjugate of entry (k, i) when TRANS; [q] real parts, [16 + q] imaginary parts
+    auto load = [&](int b, int c, double (&m)[16 * E]) {
+        const int nbb = min(NB, ncols - NB * b), nbc = min(NB, ncols - NB * c);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = TRANS ? 4 * q + l4 : 16 * w + l15;
+            const int col = TRANS ? 16 * w + l15 : 4 * q + l4;
+            bool ok;
+            int64_t off;
+            const double *__restrict__ base;
+            if (c == b) { ok = row < nbb && col <= row; off = t.dinv_off[b] + row + col * nbb; base = Dinv; }
+            else { ok = row < nbc && col < nbb; off = t.a_off + NB * c + row + (int64_t)(NB * b + col) * t.lda; base = Lx; }
+            if constexpr (E == 2) {
+                const double2 v = ok ? reinterpret_cast<const double2 *>(base)[off] : make_double2(0.0, 0.0);
+                m[q] = v.x;
+                m[16 + q] = TRANS ? -v.y : v.y;
+            } else {
+                m[q] = ok ? base[off] : 0.0;
+            }
+        }
+    };
+    {
+        // blockIdx.y: which SG_CW real columns of Y this workgroup sweeps (a group's chain is MFMA-bound on one
+        // CU -- 10 steps x 64 x 64 x nrhs -- so the right-hand sides are spread over workgroups)
+        const int j0 = blockIdx.y * SG_CW;
+        const int nj = min(SG_CW, nrhs - j0);
+        double m[NSETS][16 * E];
+#pragma unroll
+        for (int u = 0; u < NSETS; u++) {
+            const int s = TRANS ? NS - 1 - u : u;
+            if (sg_c(s) < nblk) load(sg_b(s), sg_c(s), m[u]);
+        }
+        // rows of Y the group owns -> LDS (thread: column tid % SG_CW, rows tid / SG_CW + (256 / SG_CW) i)
+        {
+            constexpr int RS = 256 / SG_CW;
+            const int j = tid % SG_CW, rq = tid / SG_CW;
+#pragma unroll
+            for (int i = 0; i < MAXBLK * NB / RS; i++) {
+                const int r = rq + RS * i;
+                Yg[r][j] = (r < ncols && j < nj) ? y0[(int64_t)r * ldr + j0 + j] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NS; u++) {
+            const int s = TRANS ? NS - 1 - u : u;
+            const int b = sg_b(s), c = sg_c(s);
+            if (c < nblk) {                                  // uniform over the workgroup
+                const int src = (TRANS || c == b) ? c : b, dst = (TRANS && c != b) ? b : c;
+                const double (&ms)[16 * E] = m[u % NSETS];
+                constexpr int NJB = SG_CW / 16;
+                v4d acc[NJB];
+#pragma unroll
+                for (int jb = 0; jb < NJB; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+#pragma unroll
+                    for (int jb = 0; jb < NJB; jb++) {
+                        if (16 * jb >= nj) break;
+                        const double *__restrict__ yr = &Yg[NB * src + 4 * q + l4][0];
+                        acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ms[q], yr[16 * jb + l15], acc[jb], 0, 0, 0);
+                        if constexpr (E == 2) {
+                            // Im(block) against the pair image: (re, im) <- (-xi, +xr); for the conjugate transpose the
+                            // sign already sits in ms[16 + q]
+                            const int j = 16 * jb + l15;
+                            const double v = yr[j ^ 1];
+                            acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ms[16 + q], (j & 1) ? v : -v, acc[jb], 0, 0, 0);
+                        }
+                    }
+                }
+                if (c == b) __syncthreads();                 // the diagonal solve overwrites the rows it has just read
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    double *__restrict__ yd = &Yg[NB * dst + 16 * w + l4 + 4 * g][0];
+#pragma unroll
+                    for (int jb = 0; jb < NJB; jb++) {
+                        if (16 * jb >= nj) break;
+                        if (c == b) yd[16 * jb + l15] = acc[jb][g]; else yd[16 * jb + l15] -= acc[jb][g];
+                    }
+                }
+                __syncthreads();
+            }
+            if (u + NSETS < NS) {
+                const int s2 = TRANS ? NS - 1 - (u + NSETS) : u + NSETS;
+                if (sg_c(s2) < nblk) load(sg_b(s2), sg_c(s2), m[u % NSETS]);
+            }
+        }
+        {
+            constexpr int RS = 256 / SG_CW;
+            const int j = tid % SG_CW, rq = tid / SG_CW;
+#pragma unroll 16
+            for (int i = 0; i < MAXBLK * NB / RS; i++) {
+                const int r = rq + RS * i;
+                if (r < ncols && j < nj) y0[(int64_t)r * ldr + j0 + j] = Yg[r][j];
             }
         }
     }
