@@ -787,7 +787,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     // name that image and its leading dimension until the transpose back
     double *const Xcol = X;
     const int64_t dcol = d;
-    const bool mma = nr >= tuning().solve_mma_min;
+    // measured crossover of the grouped scalar and MFMA sweeps: 5 right-hand sides (real), 3 (complex)
+    const bool mma = nr >= (cplx ? std::min(tuning().solve_mma_min, tuning().solve_mma_min_c) : tuning().solve_mma_min);
     const int nrr = nr * F->E;                          // real columns of the row-major image
     if (!cplx && !mma && nr <= SOLVE_NR && tuning().solve_group) {
         // few right-hand sides: the sweep is a chain of dependent launches -- two per SOLVE_GROUP blocks

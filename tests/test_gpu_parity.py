@@ -542,6 +542,36 @@ def test_solve_complex_with_permutation(engine, have_ref):
     assert relerr(L.solve(Br, 0), L.solve(Br + 0j, 0)) < 1e-14
 
 
+@pytest.mark.parametrize("kind,size", [("lap3d", 18), ("helm", 14), ("lap2d", 70)])
+def test_every_solve_path_against_the_oracle(engine, kind, size):
+    """the sweeps have four code paths -- scalar or MFMA kernels (tuning key 9), one launch pair per 64-column
+    block or solve groups of four blocks (key 10) -- and defaults that pick by nrhs and xtype: every path, for
+    few and many right-hand sides, against the oracle's sweeps on the oracle's factor"""
+    from oracle import port
+    from suitesparse_amd import problems, symbolic
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "helm": problems.helmholtz_3d}[kind](size)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    cplx = np.iscomplexobj(Sx)
+    so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx)
+    assert so == 0
+    L = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    rng = np.random.default_rng(7)
+    try:
+        for nrhs in (1, 3, 7, 20):
+            B = rng.standard_normal((p["n"], nrhs)) + (1j * rng.standard_normal((p["n"], nrhs)) if cplx else 0)
+            Yo = port.super_solve(sym, Lo, B, lower=True)
+            Xo = port.super_solve(sym, Lo, Yo, lower=False)
+            for mma_min in (1, 1000):
+                for groups in (0, 1):
+                    engine.set_tuning(9, mma_min); engine.set_tuning(10, groups)
+                    assert relerr(L.super_lsolve(B), Yo) < 1e-10, (nrhs, mma_min, groups)
+                    assert relerr(L.super_ltsolve(Yo), Xo) < 1e-10, (nrhs, mma_min, groups)
+    finally:
+        engine.set_tuning(9, 5); engine.set_tuning(10, 1)
+
+
 @pytest.mark.parametrize("kind,size,nrhs", [("lap3d", 20, 8), ("lap3d", 20, 23), ("lap2d", 90, 64), ("elast", 8, 70),
                                             ("lap3d", 28, 130)])
 def test_multi_rhs_solve_on_mfma(engine, kind, size, nrhs, have_ref):
