@@ -235,8 +235,8 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * the panel factorization above the 64-column panels (defaults 256, 1024, none); key 4: super-tile edge of the
  * tile order (1 = plain row-major); key 5: 1 = deal the tile sequence to the 8 XCDs in contiguous chunks;
  * key 9: fewest right-hand sides that run the solves on the MFMA kernels (default 5; a complex factor: min(value, 3)); key 10: 0 = no solve groups (one
- * diagonal + one update launch per 64-column block instead of two per 256 columns); key 11: tiles per run of the
- * backward solve updates = step tiles / value; key 12: 1 = look-ahead (far part of the outermost trailing updates on
+ * diagonal + one update launch per 64-column block instead of two per 256 columns); key 11 / 13: tiles per run of the
+ * backward solve updates (scalar / MFMA kernels) = step tiles / value; key 12: 1 = look-ahead (far part of the outermost trailing updates on
  * a second stream, measured +1.6 % at 150^3, off by default); keys 3 and 6: retired. */
 int mi355_set_tuning(int key, int value);
 

@@ -78,7 +78,7 @@ struct DeviceSchedule {
     DevBuf<SolveGroupTask> sgroups;
     DevBuf<PotrfTask> sutasks;
     DevBuf<int32_t> stmap;
-    DevBuf<SolveRange> sranges;
+    DevBuf<SolveRange> sranges, sranges_mma;
     bool solve_groups_ready = false;
 };
 
@@ -761,6 +761,7 @@ static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
     HIP_TRY(DS.sutasks.upload(DS.ssched.utasks.data(), DS.ssched.utasks.size(), F->stream));
     HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));
     HIP_TRY(DS.sranges.upload(DS.ssched.ranges.data(), DS.ssched.ranges.size(), F->stream));
+    HIP_TRY(DS.sranges_mma.upload(DS.ssched.ranges_mma.data(), DS.ssched.ranges_mma.size(), F->stream));
     DS.solve_groups_ready = true;
     return MI355_OK;
 }
@@ -885,11 +886,13 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                            DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, st.stiles, group,
                                            F->Lx.p, F->dLs.p, X, d, nrr, j0);
             } else {
-                if (st.stiles > 0)
+                if (st.rmcount > 0) {
+                    if (st.rmcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
                     for (int j0 = 0; j0 < nrr; j0 += 64)
-                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma<2> : k_solve_bwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, st.stiles, group,
+                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma_run<2> : k_solve_bwd_mma_run<1>, dim3((unsigned)st.rmcount),
+                                           dim3(256), 0, F->stream, DS.sutasks.p + st.ufirst, DS.sranges_mma.p + st.rmfirst,
                                            F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                }
                 group_kernel();
             }
             HIP_TRY(hipGetLastError());
@@ -1266,6 +1269,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 10) tuning().solve_group = value;
     else if (key == 11) tuning().solve_bwd_div = std::max(1, value);
     else if (key == 12) tuning().lookahead = value;
+    else if (key == 13) tuning().solve_bwd_div_mma = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -566,18 +566,23 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
             }
             // backward sweep: runs of at most `run` tiles, long enough to amortise the flush (a transpose-reduce
             // and 64 atomics into entries every run of the block hits) and short enough to leave ~512 runs
-            st.rfirst = (int64_t)out.ranges.size();
-            const int64_t run = std::min<int64_t>(32, std::max<int64_t>(2, st.stiles / std::max(1, tuning().solve_bwd_div)));
-            for (int64_t u = 0; u < st.ucount; u++) {
-                const PotrfTask &pt = out.utasks[(size_t)(st.ufirst + u)];
-                const int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
-                for (int64_t t0 = 0; t0 < nt; t0 += run) {
-                    SolveRange r;
-                    r.task = (int32_t)u; r.tile0 = (int32_t)t0; r.ntiles = (int32_t)std::min<int64_t>(run, nt - t0); r.pad = 0;
-                    out.ranges.push_back(r);
+            auto cut = [&](std::vector<SolveRange> &dst, int64_t run) {
+                for (int64_t u = 0; u < st.ucount; u++) {
+                    const PotrfTask &pt = out.utasks[(size_t)(st.ufirst + u)];
+                    const int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                    for (int64_t t0 = 0; t0 < nt; t0 += run) {
+                        SolveRange r;
+                        r.task = (int32_t)u; r.tile0 = (int32_t)t0; r.ntiles = (int32_t)std::min<int64_t>(run, nt - t0); r.pad = 0;
+                        dst.push_back(r);
+                    }
                 }
-            }
+            };
+            st.rfirst = (int64_t)out.ranges.size();
+            cut(out.ranges, std::min<int64_t>(32, std::max<int64_t>(2, st.stiles / std::max(1, tuning().solve_bwd_div))));
             st.rcount = (int64_t)out.ranges.size() - st.rfirst;
+            st.rmfirst = (int64_t)out.ranges_mma.size();
+            cut(out.ranges_mma, std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_bwd_div_mma))));
+            st.rmcount = (int64_t)out.ranges_mma.size() - st.rmfirst;
             out.steps.push_back(st);
         }
     }

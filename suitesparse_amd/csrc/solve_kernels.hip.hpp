@@ -675,6 +675,97 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
     if (cur >= 0) flush();
 }
 
+// k_solve_bwd_mma over a work list (grouped sweeps): entry = a run of consecutive row tiles of ONE block task, so
+// the loop has no task switches and is software-pipelined -- while the MFMAs of tile t run, the L entries and
+// the gathered rows of Y of tile t+1 are already in flight into registers; they go to LDS between two barriers
+// at the top of the next pass.  Complex: Im(L) stays in registers and the second product reads the
+// pair-swapped image of Y from the same LDS rows.  One set of atomics per run.
+template <int E>
+__global__ __launch_bounds__(256) void k_solve_bwd_mma_run(
+    const PotrfTask *__restrict__ tasks, const SolveRange *__restrict__ work,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
+    int nrhs, int j0)
+{
+    __shared__ double Xt[64][SM_LD];                     // Xt[j][r]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nj = min(64, nrhs - j0);
+    const SolveRange e = work[blockIdx.x];
+    const PotrfTask t = tasks[e.task];
+    const int nb = t.nb;
+    v4d acc[4];                                          // wave w: columns c = 16w + lane/16 + 4g, rhs 16 jb + lane%16
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double lr[16], li[E == 2 ? 16 : 1], xv[16];
+    // thread's share of tile tt: the MFMA A operand L[r0 + 4q + lane/16][16w + lane%16] (q = 0..15), straight from
+    // global memory (runs of 4 rows; the 4 k-steps that share a cache line are issued back to back), and
+    // Y[row(r0 + w + 4i)][j0 + lane] (i = 0..15) for the LDS image
+    auto fetch = [&](int tt) {
+        const int r0 = t.urow0 + (e.tile0 + tt) * SOLVE_ROWS;
+        const int rows_here = min(SOLVE_ROWS, t.lda - r0);
+        const int c = 16 * w + l15;
+        const int64_t coff = t.a_off + (r0 - t.col0) + (int64_t)(c < nb ? c : 0) * t.lda;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int rr = 4 * q + l4;
+            const bool ok = rr < rows_here && c < nb;
+            if constexpr (E == 2) {
+                const double2 v = ok ? reinterpret_cast<const double2 *>(Lx)[coff + rr] : make_double2(0.0, 0.0);
+                lr[q] = v.x; li[q] = v.y;
+            } else {
+                lr[q] = ok ? Lx[coff + rr] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int rr = w + 4 * i, r = r0 + rr;
+            double v = 0.0;
+            if (rr < rows_here && lane < nj) {
+                const int64_t row = (r < t.nscol) ? (int64_t)t.k1 + r : (int64_t)Ls[t.ls_off + r];
+                v = Y[row * ldr + j0 + lane];
+            }
+            xv[i] = v;
+        }
+    };
+    fetch(0);
+    for (int tt = 0; tt < e.ntiles; tt++) {
+        const int r0 = t.urow0 + (e.tile0 + tt) * SOLVE_ROWS;
+        const int nq = (min(SOLVE_ROWS, t.lda - r0) + 3) >> 2;    // k-steps of 4 rows that hold anything
+        __syncthreads();                                 // the previous tile's operand reads are done
+#pragma unroll
+        for (int i = 0; i < 16; i++) Xt[lane][w + 4 * i] = xv[i];
+        double a[16], a2[E == 2 ? 16 : 1];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { a[q] = lr[q]; if constexpr (E == 2) a2[q] = li[q]; }
+        __syncthreads();
+        if (tt + 1 < e.ntiles) fetch(tt + 1);            // in flight during the products below
+        if (16 * w < nb) {                               // wave-uniform; no barrier inside
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                if (q >= nq) break;
+#pragma unroll
+                for (int jb = 0; jb < 4; jb++) {
+                    if (16 * jb >= nj) break;
+                    const int j = 16 * jb + l15;
+                    acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], Xt[j][4 * q + l4], acc[jb], 0, 0, 0);
+                    if constexpr (E == 2) {
+                        // conj(L)^T y: (re, im) <- Li * (+yi, -yr)
+                        const double v = Xt[j ^ 1][4 * q + l4];
+                        acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], (j & 1) ? -v : v, acc[jb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    double *__restrict__ x1 = Y + (int64_t)(t.k1 + t.col0) * ldr + j0 + l15;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int c = 16 * w + l4 + 4 * g;
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++)
+            if (c < nb && 16 * jb + l15 < nj) atomic_add_f64(x1 + (int64_t)c * ldr + 16 * jb, -acc[jb][g]);
+    }
+}
+
 // x1 <- inv(L11) x1 (TRANS = false) or inv(L11)^H x1 (TRANS = true) for many right-hand sides: a 64 x 64 x nrhs
 // product per block on the MFMA pipe.  One workgroup per block; wave w owns rows [16w, 16w+16) of the result.
 template <bool TRANS, int E>

@@ -13,6 +13,8 @@ E = 2 if cplx else 1
 L = engine.SupernodalFactor(sym, xtype=E)
 L.set_matrix(Sp, Si, Sx)
 assert L.numeric() == 0
+if len(sys.argv) > 4:
+    engine.set_tuning(13, int(sys.argv[4]))
 for nrhs in [int(a) for a in sys.argv[3].split(",")]:
     out = []
     ref = None
