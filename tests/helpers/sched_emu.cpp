@@ -119,6 +119,8 @@ void emu_set_tuning(int key, int value)
     else if (key == 5) tuning().xcd_deal = value;
     else if (key == 7) tuning().ob2 = value;
     else if (key == 8) tuning().ob3 = value;
+    else if (key == 11) tuning().solve_bwd_div = value;
+    else if (key == 13) tuning().solve_bwd_div_mma = value;
 }
 
 // tile tables of the schedule built for a complex factor (rectangular big tiles): 0 if every GEMM step's table
@@ -320,5 +322,104 @@ int emu_super_solve(int lower, int64_t n, int64_t nsuper, const int64_t *Super, 
                     const double *Dinv, int64_t nrhs, double *X, int64_t d)
 {
     return emu_solve_phase(lower, n, nsuper, Super, Lpi, Lpx, Ls, ssize, xsize, Lx, Dinv, nrhs, X, d, nullptr, 0);
+}
+
+// the grouped sweeps exactly as engine.hip's solve_dev walks the SolveSchedule (schedule.hpp): per step the
+// group tasks (diagonal solves + updates among the SOLVE_GROUP blocks of a group), then the updates of the
+// rows below the group, tile by tile (forward) or run by run (backward; mma != 0: the MFMA kernel's runs).
+// Returns < 0 if the tile tables or the runs do not cover every row tile exactly once.
+int emu_super_solve_grouped(int lower, int mma, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                            const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
+                            const double *Dinv, int64_t nrhs, double *X, int64_t d)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    SolveSchedule ss; build_solve_groups(sc, ss);
+    auto group_part = [&](const SolveStep &st) {
+        for (int64_t gi = st.gfirst; gi < st.gfirst + st.gcount; gi++) {
+            const SolveGroupTask &g = ss.groups[(size_t)gi];
+            const int nblk = (g.ncols + NB - 1) / NB;
+            if (nblk > st.maxblk) return -30;
+            for (int64_t j = 0; j < nrhs; j++) {
+                double *x = X + j * d + g.x0;
+                auto diag = [&](int b) {
+                    const int nb = std::min(NB, g.ncols - NB * b);
+                    const double *D = Dinv + g.dinv_off[b];
+                    std::vector<double> y(nb, 0.0);
+                    for (int i = 0; i < nb; i++)
+                        for (int k = 0; k < nb; k++) y[i] += (lower ? D[i + k * nb] : D[k + i * nb]) * x[NB * b + k];
+                    for (int i = 0; i < nb; i++) x[NB * b + i] = y[i];
+                };
+                if (lower) {
+                    for (int b = 0; b < nblk; b++) {
+                        diag(b);
+                        for (int r = NB * (b + 1); r < g.ncols; r++)
+                            for (int k = NB * b; k < std::min(NB * (b + 1), g.ncols); k++)
+                                x[r] -= Lx[g.a_off + r + (int64_t)k * g.lda] * x[k];
+                    }
+                } else {
+                    for (int b = nblk - 1; b >= 0; b--) {
+                        for (int r = NB * (b + 1); r < g.ncols; r++)
+                            for (int k = NB * b; k < std::min(NB * (b + 1), g.ncols); k++)
+                                x[k] -= Lx[g.a_off + r + (int64_t)k * g.lda] * x[r];
+                        diag(b);
+                    }
+                }
+            }
+        }
+        return 0;
+    };
+    // one row tile of an update task
+    auto tile = [&](const PotrfTask &t, int64_t tl) {
+        for (int rr = 0; rr < SOLVE_ROWS; rr++) {
+            const int64_t r = t.urow0 + tl * SOLVE_ROWS + rr;
+            if (r >= t.lda) break;
+            const int64_t row = (r < t.nscol) ? (int64_t)t.k1 + r : Ls[t.ls_off + r];
+            for (int64_t j = 0; j < nrhs; j++) {
+                double *x = X + j * d;
+                for (int c = 0; c < t.nb; c++) {
+                    const double l = Lx[t.a_off + (r - t.col0) + (int64_t)c * t.lda];
+                    if (lower) x[row] -= l * x[t.k1 + t.col0 + c]; else x[t.k1 + t.col0 + c] -= l * x[row];
+                }
+            }
+        }
+    };
+    for (size_t ii = 0; ii < ss.steps.size(); ii++) {
+        const SolveStep &st = ss.steps[lower ? ii : ss.steps.size() - 1 - ii];
+        // every tile of every update task once: prefix sums, tile -> task table, runs
+        int64_t tiles = 0;
+        for (int64_t u = 0; u < st.ucount; u++) {
+            const PotrfTask &t = ss.utasks[(size_t)(st.ufirst + u)];
+            if (t.stile0 != tiles) return -31;
+            const int64_t nt = ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+            for (int64_t k = 0; k < nt; k++) if (ss.tile_task[(size_t)(st.tmap_off + tiles + k)] != u) return -32;
+            tiles += nt;
+        }
+        if (tiles != st.stiles) return -33;
+        if (lower) {
+            if (int rc = group_part(st)) return rc;
+            for (int64_t b = 0; b < st.stiles; b++) {
+                const PotrfTask &t = ss.utasks[(size_t)(st.ufirst + ss.tile_task[(size_t)(st.tmap_off + b)])];
+                tile(t, b - t.stile0);
+            }
+        } else {
+            const std::vector<SolveRange> &rg = mma ? ss.ranges_mma : ss.ranges;
+            const int64_t r0 = mma ? st.rmfirst : st.rfirst, rn = mma ? st.rmcount : st.rcount;
+            int64_t covered = 0;
+            for (int64_t k = r0; k < r0 + rn; k++) {
+                const SolveRange &e = rg[(size_t)k];
+                if (e.task < 0 || e.task >= st.ucount || e.ntiles <= 0) return -34;
+                const PotrfTask &t = ss.utasks[(size_t)(st.ufirst + e.task)];
+                const int64_t nt = ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                if (e.tile0 < 0 || e.tile0 + e.ntiles > nt) return -35;
+                for (int64_t q = 0; q < e.ntiles; q++) tile(t, e.tile0 + q);
+                covered += e.ntiles;
+            }
+            if (covered != st.stiles) return -36;     // (with the bounds above and the results below: exactly once)
+            if (int rc = group_part(st)) return rc;
+        }
+    }
+    return 0;
 }
 }

@@ -22,6 +22,8 @@ def emu():
     E.emu_dinv_size.restype = C.c_int64
     E.emu_super_solve.argtypes = [C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
                                   f64p, f64p, C.c_int64, f64p, C.c_int64]
+    E.emu_super_solve_grouped.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64,
+                                          C.c_int64, f64p, f64p, C.c_int64, f64p, C.c_int64]
     return E
 
 
@@ -114,6 +116,45 @@ def test_schedule_reproduces_reference(emu, name):
     Z = X.reshape(nrhs, n).T
     assert relerr(Z, g["Z"]) < 1e-8
     assert backward_error_S(g, Z) <= 10 * backward_error_S(g, g["Z"]) + 1e-18
+
+
+@pytest.mark.parametrize("kind,size,bwd_div", [("lap3d", 16, 256), ("lap3d", 12, 1), ("lap2d", 60, 4), ("elast", 6, 16),
+                                               ("dense", 700, 2)])
+def test_solve_groups_cover_every_block_and_tile(emu, kind, size, bwd_div):
+    """the grouped sweeps (build_solve_groups: groups of four blocks, per-block update tasks below the group,
+    tile tables, backward runs for the scalar and the MFMA kernel) through the emulator against the oracle"""
+    from oracle import port
+    if kind == "dense":
+        n = size
+        rng = np.random.default_rng(n)
+        M = rng.standard_normal((n, n))
+        A = M @ M.T + n * np.eye(n)
+        g = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n], dtype=np.int64),
+                 Lpi=np.array([0, n], dtype=np.int64), Lpx=np.array([0, n * n], dtype=np.int64),
+                 Ls=np.arange(n, dtype=np.int64), Sp=np.arange(n + 1, dtype=np.int64) * n,
+                 Si=np.tile(np.arange(n, dtype=np.int64), n), Sx=np.ascontiguousarray(A.T).reshape(-1), beta=0.0,
+                 maxcsize=1)
+    else:
+        from test_multigpu import problem
+        g = problem(kind, size)
+    st, minor, Lx, D = run_emu(emu, g)
+    assert st == 0
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+    n, nrhs = g["n"], 3
+    B = np.random.default_rng(1).standard_normal((n, nrhs))
+    Yo = port.super_solve(g, Lo, B, lower=True)
+    Xo = port.super_solve(g, Lo, Yo, lower=False)
+    emu.emu_set_tuning(11, bwd_div); emu.emu_set_tuning(13, bwd_div)
+    try:
+        for mma in (0, 1):
+            X = np.ascontiguousarray(B.T).reshape(-1).copy()
+            assert emu.emu_super_solve_grouped(1, mma, *a, Lx, D, nrhs, X, n) == 0
+            assert relerr(X.reshape(nrhs, n).T, Yo) < 1e-9
+            assert emu.emu_super_solve_grouped(0, mma, *a, Lx, D, nrhs, X, n) == 0
+            assert relerr(X.reshape(nrhs, n).T, Xo) < 1e-9
+    finally:
+        emu.emu_set_tuning(11, 256); emu.emu_set_tuning(13, 4096)
 
 
 def test_schedule_large_supernodes_vs_oracle(emu, have_ref):
