@@ -82,6 +82,13 @@ int mi355_factor_set_matrix(mi355_factor *handle, const int64_t *Ap, const int64
 int mi355_factor_set_matrix_zomplex(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
                                     const int64_t *Anz, const double *Ax, const double *Az);
 
+/* Stage A ITSELF (stype < 0: its lower part) together with L->Perm (NULL: identity): the assembly kernel places
+ * A(i,j) at S(max, min) of the permuted indices, conjugated when they swap, so the copy S = tril(P A P') that
+ * cholmod_factorize builds with two cholmod_ptranspose calls (CHOLMOD/Cholesky/cholmod_factorize.c:225-236)
+ * is never formed.  Same result as mi355_factor_set_matrix on that S. */
+int mi355_factor_set_matrix_perm(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
+                                 const int64_t *Anz, const double *Ax, const int64_t *Perm);
+
 /* Factorize the staged matrix: Lx (device) <- chol(S + beta*I).  *status receives
  * CHOLMOD_OK or CHOLMOD_NOT_POSDEF and *minor the reference's L->minor (n if positive
  * definite), with the reference's zeroing/repeat-supernode semantics

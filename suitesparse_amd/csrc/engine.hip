@@ -115,6 +115,8 @@ struct mi355_factor_s {
     DevBuf<int64_t> Ap, Ai, Anz;
     DevBuf<double> Ax;
     bool have_A = false, A_unpacked = false;
+    bool A_perm = false;        // the staged matrix is A itself; dIperm places it (mi355_factor_set_matrix_perm)
+    DevBuf<int64_t> dIperm;
     bool numeric_ok = false;    // a positive-definite factor is resident
     bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
     int64_t minor = 0;
@@ -220,9 +222,18 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     const bool cplx = F->E == 2;
     if (init && ncols_asm > 0) {
         const unsigned grid = (unsigned)((ncols_asm + 255) / 256);
-        hipLaunchKernelGGL(cplx ? k_assemble_c : k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
-                           F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
-                           F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta, smask);
+        if (F->A_perm) {
+            hipLaunchKernelGGL(cplx ? k_assemble_perm<2> : k_assemble_perm<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
+                               F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p, F->dIperm.p,
+                               F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, smask);
+            if (beta != 0.0)
+                hipLaunchKernelGGL(cplx ? k_add_beta<2> : k_add_beta<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm, beta,
+                                   F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->Lx.p, smask);
+        } else {
+            hipLaunchKernelGGL(cplx ? k_assemble_c : k_assemble, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
+                               F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
+                               F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, beta, smask);
+        }
         HIP_TRY(hipGetLastError());
     }
     tm.end(2);
@@ -456,6 +467,26 @@ static int set_matrix_impl(mi355_factor *F, const int64_t *Ap, const int64_t *Ai
     }
     F->A_unpacked = (Anz != nullptr);
     if (Anz) HIP_TRY(F->Anz.upload(Anz, (size_t)n, F->stream));
+    F->have_A = true;
+    F->A_perm = false;
+    return MI355_OK;
+}
+
+int mi355_factor_set_matrix_perm(mi355_factor *F, const int64_t *Ap, const int64_t *Ai, const int64_t *Anz,
+                                 const double *Ax, const int64_t *Perm)
+{
+    int rc = set_matrix_impl(F, Ap, Ai, Anz, Ax, nullptr);
+    if (rc) return rc;
+    F->have_A = false;
+    const int64_t n = F->sym.n;
+    std::vector<int64_t> iperm((size_t)n, -1);
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t pk = Perm ? Perm[k] : k;
+        if (pk < 0 || pk >= n || iperm[(size_t)pk] >= 0) return fail(MI355_INVALID, "Perm is not a permutation of 0..n-1");
+        iperm[(size_t)pk] = k;
+    }
+    HIP_TRY(F->dIperm.upload(iperm.data(), (size_t)n, F->stream));
+    F->A_perm = true;
     F->have_A = true;
     return MI355_OK;
 }

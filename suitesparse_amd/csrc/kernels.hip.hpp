@@ -71,6 +71,62 @@ __global__ __launch_bounds__(256) void k_assemble(
 }
 
 //------------------------------------------------------------------------------
+// k_assemble_perm: Lx <- tril(P A P') straight from A (stype < 0: its lower part) and the inverse permutation,
+// one thread per column of A -- the permuted copy S that cholmod_factorize builds with two ptransposes
+// (CHOLMOD/Cholesky/cholmod_factorize.c:225-236) never exists.  Entry A(i,j), i >= j, lands at
+// S(max(ki,kj), min(ki,kj)), ki = iperm[i], conjugated if the two swap; entries outside the pattern of L are
+// dropped (worker :462-467).  k_add_beta then adds beta to the diagonal (worker :510-520).
+//------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_assemble_perm(
+    int64_t ncols, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+    const int64_t *__restrict__ Anz, const double *__restrict__ Ax, const int64_t *__restrict__ iperm,
+    const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
+    const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx,
+    const int32_t *__restrict__ Ls, double *__restrict__ Lx, const int8_t *__restrict__ smask)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    const int64_t kj = iperm[j];
+    int64_t p = Ap[j];
+    const int64_t pend = Anz ? p + Anz[j] : Ap[j + 1];
+    for (; p < pend; p++) {
+        const int64_t i = Ai[p];
+        if (i < j) continue;
+        const int64_t ki = iperm[i];
+        const bool swap = ki < kj;
+        const int64_t kc = swap ? ki : kj, kr = swap ? kj : ki;
+        const int s = supermap[kc];
+        if (smask && !smask[s]) continue;
+        const int64_t k1 = Super[s], psi = Lpi[s];
+        const int nsrow = (int)(Lpi[s + 1] - psi);
+        const int imap = find_row(Ls + psi, nsrow, (int)kr);
+        if (imap < 0) continue;
+        const int64_t at = Lpx[s] + (kc - k1) * (int64_t)nsrow + imap;
+        if (E == 2) {
+            Lx[2 * at] = Ax[2 * p];
+            Lx[2 * at + 1] = swap ? -Ax[2 * p + 1] : Ax[2 * p + 1];
+        } else {
+            Lx[at] = Ax[p];
+        }
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_add_beta(
+    int64_t ncols, double beta, const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
+    const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx, double *__restrict__ Lx,
+    const int8_t *__restrict__ smask)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int s = supermap[k];
+    if (smask && !smask[s]) return;
+    const int64_t k1 = Super[s], nsrow = Lpi[s + 1] - Lpi[s];
+    Lx[E * (Lpx[s] + (k - k1) * nsrow + (k - k1))] += beta;
+}
+
+//------------------------------------------------------------------------------
 // k_relmap: relmap[rm_off + i] = position of Ls[ls_src + i] in the row list of s
 //------------------------------------------------------------------------------
 struct RelmapPair { int64_t ls_src, ls_dst, rm_off; int32_t nsrow, pad; };

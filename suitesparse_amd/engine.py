@@ -35,6 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_super_solve_phase_dev", "mi355_solve_keep_rows_dev",
+    "mi355_factor_set_matrix_perm",
     "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
@@ -89,6 +90,7 @@ def lib():
                                                  C.POINTER(C.c_int64)]
         L.mi355_super_solve_phase_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
         L.mi355_solve_keep_rows_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_factor_set_matrix_perm.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, C.c_void_p]
         L.mi355_factor_set_top_distribution.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi355_factor_top_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -178,6 +180,29 @@ class SupernodalFactor:
             pass
 
     # ---- numeric ----
+    def set_matrix_perm(self, Ap, Ai, Ax, Perm=None, Anz=None):
+        """stage A itself (lower part, stype < 0) + L->Perm: S = tril(P A P') is placed by the assembly kernel"""
+        Ap = np.ascontiguousarray(Ap, dtype=np.int64)
+        Ai = np.ascontiguousarray(Ai, dtype=np.int64)
+        if self.E == 2:
+            Ax = np.ascontiguousarray(Ax, dtype=np.complex128).view(np.float64)
+        else:
+            if np.iscomplexobj(Ax):
+                raise Mi355Error(CHOLMOD_INVALID, "complex type mismatch: complex A with a real L")
+            Ax = np.ascontiguousarray(Ax, dtype=np.float64)
+        if Ai.size == 0:
+            Ai = np.zeros(1, dtype=np.int64)
+            Ax = np.zeros(2)
+        nz = None
+        if Anz is not None:
+            self._nz = np.ascontiguousarray(Anz, dtype=np.int64)
+            nz = self._nz.ctypes.data_as(C.c_void_p)
+        pp = None
+        if Perm is not None:
+            self._perm_in = np.ascontiguousarray(Perm, dtype=np.int64)
+            pp = self._perm_in.ctypes.data_as(C.c_void_p)
+        _check(lib().mi355_factor_set_matrix_perm(self._h, Ap, Ai, nz, Ax, pp))
+
     def set_matrix(self, Sp, Si, Sx, Snz=None, Sz=None):
         """Sx: real array, or complex array (interleaved on the way in) for a complex L;
         Sz: imaginary parts of a zomplex matrix (then Sx holds the real parts)."""

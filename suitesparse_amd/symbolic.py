@@ -93,6 +93,9 @@ def permute(sym, Ap, Ai, Ax):
     cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
     a, b = pinv[np.asarray(Ai)], pinv[cols]
     r, c = np.maximum(a, b), np.minimum(a, b)
-    S = sp.csc_matrix((np.asarray(Ax), (r, c)), shape=(n, n))
+    v = np.asarray(Ax)
+    if np.iscomplexobj(v):
+        v = np.where(a < b, v.conj(), v)        # A(i,j) moves to the upper part: its lower mirror is the conjugate
+    S = sp.csc_matrix((v, (r, c)), shape=(n, n))
     S.sort_indices()
     return S.indptr.astype(np.int64), S.indices.astype(np.int64), np.ascontiguousarray(S.data)

@@ -542,6 +542,37 @@ def test_solve_complex_with_permutation(engine, have_ref):
     assert relerr(L.solve(Br, 0), L.solve(Br + 0j, 0)) < 1e-14
 
 
+@pytest.mark.parametrize("kind,size,beta", [("lap3d", 14, 0.0), ("helm", 10, 0.5), ("elast", 5, 0.0), ("lap2d", 50, 1.0)])
+def test_device_side_permutation_matches_host_permutation(engine, kind, size, beta):
+    """mi355_factor_set_matrix_perm (A + Perm, S = tril(P A P') placed by the assembly kernel)
+    against mi355_factor_set_matrix on the host-permuted S, and against the oracle"""
+    from oracle import port
+    from suitesparse_amd import problems, symbolic
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "helm": problems.helmholtz_3d,
+         "elast": problems.elasticity27}[kind](size)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    cplx = np.iscomplexobj(Sx)
+    so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx, beta=beta)
+    assert so == 0
+    L1 = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    L1.set_matrix(Sp, Si, Sx)
+    assert L1.numeric(beta=beta) == 0
+    L2 = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    L2.set_matrix_perm(p["Ap"], p["Ai"], p["Ax"], sym["Perm"])
+    assert L2.numeric(beta=beta) == 0
+    assert relerr(L2.Lx(), L1.Lx()) < 1e-13
+    assert relerr(L2.Lx(), Lo) < TOL_L
+    # refactorization from the staged A; identity permutation; a bad permutation
+    assert L2.numeric(beta=beta) == 0 and relerr(L2.Lx(), Lo) < TOL_L
+    L3 = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    L3.set_matrix_perm(Sp, Si, Sx, None)
+    assert L3.numeric(beta=beta) == 0 and relerr(L3.Lx(), Lo) < TOL_L
+    bad = np.array(sym["Perm"]).copy(); bad[0] = bad[1]
+    with pytest.raises(engine.Mi355Error):
+        L3.set_matrix_perm(p["Ap"], p["Ai"], p["Ax"], bad)
+
+
 @pytest.mark.parametrize("kind,size", [("lap3d", 18), ("helm", 14), ("lap2d", 70)])
 def test_every_solve_path_against_the_oracle(engine, kind, size):
     """the sweeps have four code paths -- scalar or MFMA kernels (tuning key 9), one launch pair per 64-column

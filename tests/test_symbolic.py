@@ -58,12 +58,15 @@ def test_nd_order_is_a_permutation(shape, dof):
     assert perm.shape == (n,) and np.array_equal(np.sort(perm), np.arange(n))
 
 
-@pytest.mark.parametrize("kind,size", [("lap3d", 17), ("lap2d", 90), ("elast", 6)])
+@pytest.mark.parametrize("kind,size", [("lap3d", 17), ("lap2d", 90), ("elast", 6), ("helm", 9)])
 def test_symbolic_vs_live_reference(kind, size, have_ref):
+    """structure bit-exact; S = tril(P A P') equal to the reference's, complex values included (an entry that
+    moves across the diagonal is conjugated)"""
     if not have_ref:
         pytest.skip("oracle/_ref not available")
     from oracle.refcholmod import RefCholmod
-    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "elast": problems.elasticity27}[kind](size)
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "elast": problems.elasticity27,
+         "helm": problems.helmholtz_3d}[kind](size)
     perm = symbolic.nd_grid_order(p["shape"], p["dof"])
     sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], perm)
     r = RefCholmod()
