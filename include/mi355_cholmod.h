@@ -99,6 +99,12 @@ int mi355_factor_numeric(mi355_factor *handle, double beta_re,
 /* Copy the numeric factor to the host array L->x (E*xsize doubles). */
 int mi355_factor_get_Lx(mi355_factor *handle, double *Lx);
 
+/* cholmod_rcond on the device-resident factor (CHOLMOD/Cholesky/cholmod_rcond.c:51-110, supernodal LL' branch of
+ * t_cholmod_rcond_worker.c:76-99,132-137): (min L(j,j) / max L(j,j))^2 over the real parts of the diagonal, 0 if one
+ * of them is NaN or the last factorization was not positive definite, 1 for n = 0.  Reads n doubles of HBM; the
+ * factor need not be copied to the host for it. */
+int mi355_factor_rcond(mi355_factor *handle, double *rcond);
+
 /* One call = cholmod_super_numeric's numeric part for (int64, double, real, stype<0):
  * set_matrix + numeric + get_Lx on an existing handle (create it once per analyze). */
 int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,

@@ -300,6 +300,13 @@ int ref_super_solve (void *hv, int lower, int64_t nrhs, double *Xx, int64_t d)
     return ok ? 0 : -2 ;
 }
 
+// cholmod_l_rcond of the current factor
+double ref_rcond (void *hv)
+{
+    ref_ctx *h = hv ;
+    return cholmod_l_rcond (h->L, &h->cm) ;
+}
+
 // X = A\B through cholmod_l_solve (CHOLMOD_A); B, X: n x nrhs, ld n, xtype of L
 int ref_solve (void *hv, int64_t nrhs, const double *Bx, double *Xx)
 {

@@ -218,6 +218,11 @@ class RefCholmod:
             return flat.view(np.complex128).reshape(nrhs, n).T.copy()
         return flat.reshape(nrhs, n).T.copy()
 
+    def rcond(self):
+        self.L.ref_rcond.restype = C.c_double
+        self.L.ref_rcond.argtypes = [C.c_void_p]
+        return float(self.L.ref_rcond(self.h))
+
     def solve(self, B):
         B = np.asarray(B)
         if B.ndim == 1:

@@ -119,6 +119,7 @@ struct mi355_factor_s {
     DevBuf<int64_t> dIperm;
     bool numeric_ok = false;    // a positive-definite factor is resident
     bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
+    bool not_posdef = false;    // the last mi355_factor_numeric stopped at a bad pivot (L->minor < n)
     int64_t minor = 0;
     // instrumentation
     int profile = 0;
@@ -442,6 +443,7 @@ static int set_matrix_impl(mi355_factor *F, const int64_t *Ap, const int64_t *Ai
     if (rc) return rc;
     const int64_t n = F->sym.n;
     F->have_A = false;
+    F->not_posdef = false;
     if (n == 0) { F->have_A = true; return MI355_OK; }
     if (!Ap || !Ai || !Ax) return fail(MI355_INVALID, "null matrix array");
     // extent of Ai/Ax actually referenced
@@ -573,6 +575,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     tm.pending = tm.on;
     F->minor = minor_out;
     F->numeric_ok = (st_out == MI355_STATUS_OK);
+    F->not_posdef = (st_out == MI355_STATUS_NOT_POSDEF);
     if (minor) *minor = minor_out;
     if (status) *status = st_out;
     return MI355_OK;
@@ -588,6 +591,66 @@ int mi355_factor_get_Lx(mi355_factor *F, double *Lx)
         HIP_TRY(hipMemcpyAsync(Lx, F->Lx.p, (size_t)F->sym.xsize * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
         HIP_TRY(hipStreamSynchronize(F->stream));
     }
+    return MI355_OK;
+}
+
+// min / max / any-NaN of the diagonal of L, one partial triple per workgroup (cholmod_rcond,
+// CHOLMOD/Cholesky/t_cholmod_rcond_worker.c:76-99: the real part of L(j,j) of every supernode column)
+__global__ __launch_bounds__(256) void k_diag_minmax(int64_t n, int E, const int32_t *__restrict__ supermap,
+                                                     const int64_t *__restrict__ Super, const int64_t *__restrict__ Lpi,
+                                                     const int64_t *__restrict__ Lpx, const double *__restrict__ Lx,
+                                                     double *__restrict__ part)
+{
+    __shared__ double smin[256], smax[256], snan[256];
+    double lo = INFINITY, hi = -INFINITY, bad = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const int s = supermap[k];
+        const int64_t jj = k - Super[s], nsrow = Lpi[s + 1] - Lpi[s];
+        const double v = Lx[E * (Lpx[s] + jj + jj * nsrow)];
+        if (v != v) bad = 1.0;
+        lo = fmin(lo, v); hi = fmax(hi, v);
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi; snan[threadIdx.x] = bad;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + h]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + h]);
+            snan[threadIdx.x] = fmax(snan[threadIdx.x], snan[threadIdx.x + h]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = smin[0]; part[3 * blockIdx.x + 1] = smax[0]; part[3 * blockIdx.x + 2] = snan[0]; }
+}
+
+int mi355_factor_rcond(mi355_factor *F, double *rcond)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!rcond) return fail(MI355_INVALID, "null rcond");
+    const Symbolic &S = F->sym;
+    if (S.n == 0) { *rcond = 1.0; return MI355_OK; }                      // cholmod_rcond.c:73-76
+    if (!F->numeric_ok) {
+        if (F->not_posdef) { *rcond = 0.0; return MI355_OK; }             // L->minor < n, :77-80
+        return fail(MI355_INVALID, "no numeric factor is resident");
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(1024, (S.n + 255) / 256);
+    DevBuf<double> part;
+    HIP_TRY(part.alloc((size_t)grid * 3));
+    hipLaunchKernelGGL(k_diag_minmax, dim3(grid), dim3(256), 0, F->stream, S.n, F->E, F->dSupermap.p, F->dSuper.p,
+                       F->dLpi.p, F->dLpx.p, F->Lx.p, part.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> h((size_t)grid * 3);
+    HIP_TRY(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    double lo = INFINITY, hi = -INFINITY;
+    for (unsigned b = 0; b < grid; b++) {
+        if (h[3 * b + 2] != 0.0) { *rcond = 0.0; return MI355_OK; }       // a NaN on the diagonal
+        lo = std::min(lo, h[3 * b]); hi = std::max(hi, h[3 * b + 1]);
+    }
+    const double r = lo / hi;
+    *rcond = r * r;                                                        // LL': (lmin / lmax)^2
     return MI355_OK;
 }
 

@@ -35,7 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_super_solve_phase_dev", "mi355_solve_keep_rows_dev",
-    "mi355_factor_set_matrix_perm",
+    "mi355_factor_set_matrix_perm", "mi355_factor_rcond",
     "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
@@ -180,6 +180,14 @@ class SupernodalFactor:
             pass
 
     # ---- numeric ----
+    def rcond(self):
+        """cholmod_rcond of the resident factor"""
+        out = C.c_double(0.0)
+        f = lib().mi355_factor_rcond
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _check(f(self._h, C.byref(out)))
+        return out.value
+
     def set_matrix_perm(self, Ap, Ai, Ax, Perm=None, Anz=None):
         """stage A itself (lower part, stype < 0) + L->Perm: S = tril(P A P') is placed by the assembly kernel"""
         Ap = np.ascontiguousarray(Ap, dtype=np.int64)

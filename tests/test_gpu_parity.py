@@ -573,6 +573,37 @@ def test_device_side_permutation_matches_host_permutation(engine, kind, size, be
         L3.set_matrix_perm(p["Ap"], p["Ai"], p["Ax"], bad)
 
 
+@pytest.mark.parametrize("kind,size", [("lap3d", 12), ("helm", 9), ("elast", 5)])
+def test_rcond_on_the_device_factor(engine, kind, size, have_ref):
+    """mi355_factor_rcond against cholmod_l_rcond of the reference's factor, the
+    not-positive-definite and empty cases as cholmod_rcond.c:73-80"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = {"lap3d": problems.laplacian_3d, "helm": problems.helmholtz_3d, "elast": problems.elasticity27}[kind](size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    cplx = np.iscomplexobj(Sx)
+    L = engine.SupernodalFactor(r.symbolic(), xtype=2 if cplx else 1)
+    with pytest.raises(engine.Mi355Error):
+        L.rcond()                                   # nothing factorized yet
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    want = r.rcond()
+    assert 0 < want < 1 and abs(L.rcond() - want) <= 1e-12 * want
+    # not positive definite: 0
+    Sx2 = np.array(Sx).copy()
+    Sx2[Sp[p["n"] // 2]] = -3.0
+    assert L.super_numeric(Sp, Si, Sx2) == 1
+    assert L.rcond() == 0.0
+    empty = dict(n=0, nsuper=0, ssize=0, xsize=0, Super=np.zeros(1, np.int64), Lpi=np.zeros(1, np.int64),
+                 Lpx=np.zeros(1, np.int64), Ls=np.zeros(0, np.int64))
+    assert engine.SupernodalFactor(empty).rcond() == 1.0
+
+
 @pytest.mark.parametrize("kind,size", [("lap3d", 18), ("helm", 14), ("lap2d", 70)])
 def test_every_solve_path_against_the_oracle(engine, kind, size):
     """the sweeps have four code paths -- scalar or MFMA kernels (tuning key 9), one launch pair per 64-column
