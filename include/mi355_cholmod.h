@@ -105,6 +105,15 @@ int mi355_factor_get_Lx(mi355_factor *handle, double *Lx);
  * factor need not be copied to the host for it. */
 int mi355_factor_rcond(mi355_factor *handle, double *rcond);
 
+/* The resident supernodal factor as a packed, monotonic simplicial one (cholmod_change_factor to simplicial numeric:
+ * super_num_to_simplicial_num, CHOLMOD/Utility/t_cholmod_change_factor.c:875-1065 and
+ * t_cholmod_change_factor_3_template.c): Lp[n+1], Li[lnz], Lnz[n] from the symbolic structure,
+ * Lx[E*lnz] packed on the device (to_ll != 0: LL'; 0: LDL' with D(j,j) = L(j,j)^2 and unit-scaled columns) and
+ * copied to the host -- lnz instead of xsize entries cross PCIe.  Any of Lp, Li, Lnz may be NULL; Lx == NULL
+ * returns the pattern and *lnz only. */
+int mi355_factor_to_simplicial(mi355_factor *handle, int to_ll, int64_t *Lp, int64_t *Li, int64_t *Lnz,
+                               double *Lx, int64_t *lnz);
+
 /* One call = cholmod_super_numeric's numeric part for (int64, double, real, stype<0):
  * set_matrix + numeric + get_Lx on an existing handle (create it once per analyze). */
 int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,

@@ -300,6 +300,29 @@ int ref_super_solve (void *hv, int lower, int64_t nrhs, double *Xx, int64_t d)
     return ok ? 0 : -2 ;
 }
 
+// packed monotonic simplicial copy of the current factor (cholmod_l_change_factor on a copy): sizes first
+// (Lx == NULL), then the arrays
+int ref_to_simplicial (void *hv, int to_ll, int64_t *Lp, int64_t *Li, int64_t *Lnz, double *Lx, int64_t *lnz)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L2 = cholmod_l_copy_factor (h->L, &h->cm) ;
+    if (!L2) return -1 ;
+    if (!cholmod_l_change_factor (L2->xtype, to_ll, 0, 1, 1, L2, &h->cm)) { cholmod_l_free_factor (&L2, &h->cm) ; return -2 ; }
+    int64_t n = L2->n ;
+    int64_t nz = ((int64_t *) L2->p) [n] ;
+    int E = (L2->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    *lnz = nz ;
+    if (Lx)
+    {
+        memcpy (Lp, L2->p, (n+1) * sizeof (int64_t)) ;
+        memcpy (Lnz, L2->nz, n * sizeof (int64_t)) ;
+        memcpy (Li, L2->i, nz * sizeof (int64_t)) ;
+        memcpy (Lx, L2->x, nz * E * sizeof (double)) ;
+    }
+    cholmod_l_free_factor (&L2, &h->cm) ;
+    return 0 ;
+}
+
 // cholmod_l_rcond of the current factor
 double ref_rcond (void *hv)
 {

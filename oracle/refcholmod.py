@@ -218,6 +218,23 @@ class RefCholmod:
             return flat.view(np.complex128).reshape(nrhs, n).T.copy()
         return flat.reshape(nrhs, n).T.copy()
 
+    def to_simplicial(self, to_ll=True):
+        """(Lp, Li, Lnz, Lx) after cholmod_l_change_factor (simplicial, packed, monotonic) on a copy of L"""
+        f = self.L.ref_to_simplicial
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lnz = C.c_int64(0)
+        if f(self.h, int(bool(to_ll)), None, None, None, None, C.byref(lnz)) != 0:
+            raise RuntimeError("ref_to_simplicial failed")
+        inf = self.info()
+        n, E = int(inf["n"]), (2 if inf["xtype"] == 2 else 1)
+        Lp = np.zeros(n + 1, dtype=np.int64); Li = np.zeros(max(lnz.value, 1), dtype=np.int64)
+        Lnz = np.zeros(max(n, 1), dtype=np.int64); Lx = np.zeros(max(lnz.value, 1) * E)
+        if f(self.h, int(bool(to_ll)), Lp.ctypes.data_as(C.c_void_p), Li.ctypes.data_as(C.c_void_p),
+             Lnz.ctypes.data_as(C.c_void_p), Lx.ctypes.data_as(C.c_void_p), C.byref(lnz)) != 0:
+            raise RuntimeError("ref_to_simplicial failed")
+        Lx = Lx[:lnz.value * E]
+        return Lp, Li[:lnz.value], Lnz[:n], (Lx.view(np.complex128) if E == 2 else Lx)
+
     def rcond(self):
         self.L.ref_rcond.restype = C.c_double
         self.L.ref_rcond.argtypes = [C.c_void_p]

@@ -594,6 +594,81 @@ int mi355_factor_get_Lx(mi355_factor *F, double *Lx)
     return MI355_OK;
 }
 
+// supernodal -> packed simplicial values (super_num_to_simplicial_num, CHOLMOD/Utility/t_cholmod_change_factor.c:875
+// and t_cholmod_change_factor_3_template.c:13-112): one workgroup per column j = k1 + jj copies rows jj .. nsrow-1 of
+// supernode column jj to out[Lp[j] ...]; LDL' (to_ll == 0): D(j,j) = L(j,j)^2 with a zero imaginary part and
+// L(i,j) / L(j,j) below it, a column whose pivot is <= 0 left as it is (:54-72).
+__global__ __launch_bounds__(256) void k_to_simplicial(int64_t n, int E, int to_ll, const int32_t *__restrict__ supermap,
+                                                       const int64_t *__restrict__ Super, const int64_t *__restrict__ Lpi,
+                                                       const int64_t *__restrict__ Lpx, const int64_t *__restrict__ Lp,
+                                                       const double *__restrict__ Lx, double *__restrict__ out)
+{
+    const int64_t j = blockIdx.x;
+    if (j >= n) return;
+    const int s = supermap[j];
+    const int64_t jj = j - Super[s], nsrow = Lpi[s + 1] - Lpi[s];
+    const double *__restrict__ src = Lx + E * (Lpx[s] + jj + jj * nsrow);       // L(j,j)
+    double *__restrict__ dst = out + E * Lp[j];
+    const int64_t len = nsrow - jj;
+    double ljj = 1.0;
+    int64_t first = 0;
+    if (!to_ll) {
+        const double d = src[0];
+        if (threadIdx.x == 0) {
+            dst[0] = (d <= 0.0) ? d : d * d;
+            if (E == 2) dst[1] = 0.0;
+        }
+        ljj = (d <= 0.0) ? 1.0 : d;
+        first = 1;
+    }
+    for (int64_t i = first + threadIdx.x; i < len; i += 256) {
+        if (E == 2) {
+            dst[2 * i] = to_ll ? src[2 * i] : src[2 * i] / ljj;
+            dst[2 * i + 1] = to_ll ? src[2 * i + 1] : src[2 * i + 1] / ljj;
+        } else {
+            dst[i] = to_ll ? src[i] : src[i] / ljj;
+        }
+    }
+}
+
+int mi355_factor_to_simplicial(mi355_factor *F, int to_ll, int64_t *Lp, int64_t *Li, int64_t *Lnz, double *Lx,
+                               int64_t *lnz_out)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const Symbolic &S = F->sym;
+    const int64_t n = S.n;
+    // pattern: pure symbolic work on the host copy of the supernodal structure
+    std::vector<int64_t> lp((size_t)n + 1, 0);
+    int64_t p = 0;
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        const int64_t k1 = S.Super[s], nscol = S.Super[s + 1] - k1, psi = S.Lpi[s], nsrow = S.Lpi[s + 1] - psi;
+        for (int64_t jj = 0; jj < nscol; jj++) {
+            lp[(size_t)(k1 + jj)] = p;
+            if (Lnz) Lnz[k1 + jj] = nsrow - jj;
+            if (Li) for (int64_t ii = jj; ii < nsrow; ii++) Li[p + ii - jj] = S.Ls[psi + ii];
+            p += nsrow - jj;
+        }
+    }
+    lp[(size_t)n] = p;
+    if (lnz_out) *lnz_out = p;
+    if (Lp) memcpy(Lp, lp.data(), ((size_t)n + 1) * sizeof(int64_t));
+    if (!Lx || n == 0) return MI355_OK;
+    if (!F->numeric_ok) return fail(MI355_INVALID, "no positive-definite numeric factor is resident");
+    if (n > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many columns for one launch");
+    DevBuf<int64_t> dLp;
+    DevBuf<double> dOut;
+    HIP_TRY(dLp.upload(lp.data(), (size_t)n + 1, F->stream));
+    HIP_TRY(dOut.alloc((size_t)p * F->E));
+    hipLaunchKernelGGL(k_to_simplicial, dim3((unsigned)n), dim3(256), 0, F->stream, n, F->E, to_ll, F->dSupermap.p,
+                       F->dSuper.p, F->dLpi.p, F->dLpx.p, dLp.p, F->Lx.p, dOut.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(Lx, dOut.p, (size_t)p * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
+}
+
 // min / max / any-NaN of the diagonal of L, one partial triple per workgroup (cholmod_rcond,
 // CHOLMOD/Cholesky/t_cholmod_rcond_worker.c:76-99: the real part of L(j,j) of every supernode column)
 __global__ __launch_bounds__(256) void k_diag_minmax(int64_t n, int E, const int32_t *__restrict__ supermap,
@@ -970,7 +1045,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
 #undef MI355_SGM_MB
 #undef MI355_SGM
             };
-            const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+            const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_fwd_div_mma)));
             const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
             if (lower) {
                 group_kernel();
@@ -1364,6 +1439,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 11) tuning().solve_bwd_div = std::max(1, value);
     else if (key == 12) tuning().lookahead = value;
     else if (key == 13) tuning().solve_bwd_div_mma = std::max(1, value);
+    else if (key == 14) tuning().solve_fwd_div_mma = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -35,7 +35,7 @@ EXPORTS = [
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
     "mi355_factor_set_partition", "mi355_factor_numeric_phase",
     "mi355_super_solve_phase_dev", "mi355_solve_keep_rows_dev",
-    "mi355_factor_set_matrix_perm", "mi355_factor_rcond",
+    "mi355_factor_set_matrix_perm", "mi355_factor_rcond", "mi355_factor_to_simplicial",
     "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
@@ -180,6 +180,21 @@ class SupernodalFactor:
             pass
 
     # ---- numeric ----
+    def to_simplicial(self, to_ll=True):
+        """(Lp, Li, Lnz, Lx) of the packed simplicial LL' (or LDL') form of the resident factor"""
+        f = lib().mi355_factor_to_simplicial
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lnz = C.c_int64(0)
+        _check(f(self._h, int(bool(to_ll)), None, None, None, None, C.byref(lnz)))
+        Lp = np.zeros(self.n + 1, dtype=np.int64)
+        Li = np.zeros(max(lnz.value, 1), dtype=np.int64)
+        Lnz = np.zeros(max(self.n, 1), dtype=np.int64)
+        Lx = np.zeros(max(lnz.value, 1) * self.E)
+        _check(f(self._h, int(bool(to_ll)), Lp.ctypes.data_as(C.c_void_p), Li.ctypes.data_as(C.c_void_p),
+                 Lnz.ctypes.data_as(C.c_void_p), Lx.ctypes.data_as(C.c_void_p), C.byref(lnz)))
+        Lx = Lx[:lnz.value * self.E]
+        return Lp, Li[:lnz.value], Lnz[:self.n], (Lx.view(np.complex128) if self.E == 2 else Lx)
+
     def rcond(self):
         """cholmod_rcond of the resident factor"""
         out = C.c_double(0.0)

@@ -573,6 +573,31 @@ def test_device_side_permutation_matches_host_permutation(engine, kind, size, be
         L3.set_matrix_perm(p["Ap"], p["Ai"], p["Ax"], bad)
 
 
+@pytest.mark.parametrize("kind,size", [("lap3d", 11), ("helm", 8), ("lap2d", 40)])
+def test_supernodal_to_simplicial_on_the_device(engine, kind, size, have_ref):
+    """mi355_factor_to_simplicial against cholmod_l_change_factor of the reference applied to
+    the SAME supernodal values (the GPU's Lx handed to the reference factor): pattern and values bit-exact,
+    LL' and LDL'"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available on this box")
+    from oracle.refcholmod import RefCholmod
+    from suitesparse_amd import problems
+    p = {"lap3d": problems.laplacian_3d, "helm": problems.helmholtz_3d, "lap2d": problems.laplacian_2d}[kind](size)
+    r = RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze("metis")
+    Sp, Si, Sx = r.permuted()
+    assert r.factorize() == 0
+    cplx = np.iscomplexobj(Sx)
+    L = engine.SupernodalFactor(r.symbolic(), xtype=2 if cplx else 1)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    r.set_Lx(L.Lx())
+    for to_ll in (True, False):
+        got, want = L.to_simplicial(to_ll), r.to_simplicial(to_ll)
+        for a, b, name in zip(got, want, ("Lp", "Li", "Lnz", "Lx")):
+            assert a.shape == b.shape and np.array_equal(a, b), (to_ll, name)
+
+
 @pytest.mark.parametrize("kind,size", [("lap3d", 12), ("helm", 9), ("elast", 5)])
 def test_rcond_on_the_device_factor(engine, kind, size, have_ref):
     """mi355_factor_rcond against cholmod_l_rcond of the reference's factor, the

@@ -14,7 +14,7 @@ L = engine.SupernodalFactor(sym, xtype=E)
 L.set_matrix(Sp, Si, Sx)
 assert L.numeric() == 0
 if len(sys.argv) > 4:
-    engine.set_tuning(13, int(sys.argv[4]))
+    engine.set_tuning(int(sys.argv[5]) if len(sys.argv) > 5 else 13, int(sys.argv[4]))
 for nrhs in [int(a) for a in sys.argv[3].split(",")]:
     out = []
     ref = None
