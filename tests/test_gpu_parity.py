@@ -280,22 +280,24 @@ def test_multigpu_phases_simulated_on_one_gpu(engine, world):
         assert relerr(X.cpu().numpy(), want) < 1e-10
 
 
-@pytest.mark.parametrize("world,ob,ob2,size", [(2, 64, 128, 16), (4, 64, 64, 16), (3, 256, 1024, 24)])
-def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size):
+@pytest.mark.parametrize("world,ob,ob2,size,kind", [(2, 64, 128, 16, "lap3d"), (4, 64, 64, 16, "lap3d"),
+                                                     (3, 256, 1024, 24, "lap3d"), (3, 64, 128, 12, "helm")])
+def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size, kind):
     """owner-computes top (mi355_factor_set_top_distribution / _top_plan / _top_run) with `world` handles on
     one GPU; the broadcasts and the sums are done by hand on the device views RCCL would use"""
     import torch
     from oracle import port
     from suitesparse_amd import multigpu
     from test_multigpu import problem
-    g = problem("lap3d", size)
+    g = problem(kind, size)
     n = g["n"]
+    cplx = np.iscomplexobj(g["Sx"])
     so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
     engine.set_tuning(2, ob); engine.set_tuning(7, ob2)
     try:
         runs = []
         for r in range(world):
-            L = engine.SupernodalFactor(g)
+            L = engine.SupernodalFactor(g, xtype=2 if cplx else 1)
             L.set_matrix(g["Sp"], g["Si"], g["Sx"])
             runs.append(multigpu.PartitionedFactor(L, g, r, world, allreduce=lambda t: None, distribute_top=True,
                                                    min_subtrees_per_rank=1))
@@ -336,8 +338,10 @@ def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size):
                     a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
                     assert relerr(Lx[a:b], Lo[a:b]) < TOL_L, (r, s)
         B = np.random.default_rng(2).standard_normal((3, n))
+        if cplx:
+            B = B + 1j * np.random.default_rng(3).standard_normal((3, n))
         want = port.super_solve(g, Lo, port.super_solve(g, Lo, B.T.copy(), lower=True), lower=False).T
-        Xs = [torch.from_numpy(B.copy()).cuda() for _ in range(world)]
+        Xs = [torch.from_numpy(np.ascontiguousarray(B).view(np.float64).copy()).cuda() for _ in range(world)]
 
         def summed():
             torch.cuda.synchronize()
@@ -356,7 +360,9 @@ def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size):
             rn.f.keep_rows_dev(x.data_ptr(), 3, n)
         summed()
         for x in Xs:
-            assert relerr(x.cpu().numpy(), want) < 1e-10
+            got = x.cpu().numpy()
+            got = got.view(np.complex128) if cplx else got
+            assert relerr(got.reshape(3, n), want) < 1e-10
     finally:
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
 

@@ -120,7 +120,8 @@ class EmuFactor:
 
 def problem(kind="lap3d", size=12):
     from suitesparse_amd import problems, symbolic
-    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "elast": problems.elasticity27}[kind](size)
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "elast": problems.elasticity27,
+         "helm": problems.helmholtz_3d}[kind](size)
     sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
     Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
     g = dict(sym, Sp=Sp, Si=Si, Sx=Sx, beta=0.0)
