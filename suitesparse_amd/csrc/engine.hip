@@ -139,6 +139,13 @@ __global__ void k_first_info(int64_t nsuper, const int *__restrict__ info, int *
 int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
 {
     Schedule &S = D.sched;
+    {
+        // no task may point outside the arrays the kernels index with it (a GPU memory fault takes the machine down)
+        Schedule ext = S;                              // Dinv is sized by the full schedule (all blocks)
+        ext.dinv_size = std::max<int64_t>(S.dinv_size, F->full.sched.dinv_size);
+        const std::string bad = check_schedule_bounds(F->sym, ext);
+        if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: schedule rejected before upload: " + bad);
+    }
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
     HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_tab.data(), S.gemm_tile_tab.size(), F->stream));
@@ -926,6 +933,12 @@ static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
 {
     if (DS.solve_groups_ready) return MI355_OK;
     build_solve_groups(DS.sched, DS.ssched);
+    {
+        Schedule ext;                                  // tasks already checked at upload: only the solve work lists here
+        ext.dinv_size = std::max<int64_t>(DS.sched.dinv_size, F->full.sched.dinv_size);
+        const std::string bad = check_schedule_bounds(F->sym, ext, &DS.ssched);
+        if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: solve work lists rejected before upload: " + bad);
+    }
     HIP_TRY(DS.sgroups.upload(DS.ssched.groups.data(), DS.ssched.groups.size(), F->stream));
     HIP_TRY(DS.sutasks.upload(DS.ssched.utasks.data(), DS.ssched.utasks.size(), F->stream));
     HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));

@@ -588,4 +588,110 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
     }
 }
 
+std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss)
+{
+    char buf[256];
+    const int64_t xs = S.xsize, ds = sc.dinv_size, rs = sc.relmap_size, ssz = S.Lpi ? S.Lpi[S.nsuper] : 0;
+    auto bad = [&](const char *what, int64_t i) { snprintf(buf, sizeof buf, "%s %lld out of bounds", what, (long long)i); return std::string(buf); };
+    // last entry a column-major block (rows x cols, ld) reaches, from off
+    auto last = [](int64_t off, int64_t rows, int64_t cols, int64_t ld) { return off + (rows - 1) + (cols - 1) * ld; };
+    for (size_t i = 0; i < sc.gemm.size(); i++) {
+        const GemmTask &t = sc.gemm[i];
+        if (t.M <= 0 || t.N <= 0 || t.K <= 0 || t.lda < t.M || t.ldc <= 0) return bad("gemm task shape", (int64_t)i);
+        if (t.a_off < 0 || last(t.a_off, t.M, t.K, t.lda) >= xs) return bad("gemm task A", (int64_t)i);
+        if (t.mode == GEMM_OVERWRITE) {
+            if (t.b_off < 0 || last(t.b_off, t.N, t.K, t.ldb) >= ds) return bad("gemm task B (Dinv)", (int64_t)i);
+        } else {
+            if (t.N > t.M) return bad("gemm task N > M", (int64_t)i);
+            if (t.b_off < 0 || last(t.b_off, t.N, t.K, t.ldb) >= xs) return bad("gemm task B", (int64_t)i);
+        }
+        if (t.mode == GEMM_SCATTER_SUB) {
+            if (t.rm_off < 0 || t.rm_off + t.M > rs) return bad("gemm task relative map", (int64_t)i);
+            if (t.c_off < 0 || t.c_off >= xs) return bad("gemm task C", (int64_t)i);
+        } else {
+            if (t.c_off < 0 || last(t.c_off, t.M, t.N, t.ldc) >= xs) return bad("gemm task C", (int64_t)i);
+        }
+    }
+    for (size_t i = 0; i < sc.potrf.size(); i++) {
+        const PotrfTask &t = sc.potrf[i];
+        if (t.nb <= 0 || t.nb > NB || t.lda < t.nb) return bad("potrf task shape", (int64_t)i);
+        if (t.a_off < 0 || last(t.a_off, t.nb, t.nb, t.lda) >= xs) return bad("potrf task A", (int64_t)i);
+        if (t.dinv_off >= 0 && t.dinv_off + (int64_t)t.nb * t.nb > ds) return bad("potrf task Dinv", (int64_t)i);
+        if (t.s < 0 || t.s >= S.nsuper || t.ls_off < 0 || t.ls_off + t.lda > ssz) return bad("potrf task rows", (int64_t)i);
+        if (t.urow0 < 0 || t.urow0 > t.lda || (int64_t)t.k1 + t.col0 + t.nb > S.n) return bad("potrf task columns", (int64_t)i);
+    }
+    for (size_t i = 0; i < sc.steps.size(); i++) {
+        const Step &st = sc.steps[i];
+        if (st.first < 0 || st.count < 0) return bad("step range", (int64_t)i);
+        if (st.kind == STEP_POTRF) {
+            if (st.first + st.count > (int64_t)sc.potrf.size()) return bad("potrf step range", (int64_t)i);
+            if (st.tmap_off < 0 || st.tmap_off + st.stiles > (int64_t)sc.solve_tile_task.size()) return bad("potrf step solve tiles", (int64_t)i);
+            for (int64_t b = 0; b < st.stiles; b++) {
+                const int32_t ti = sc.solve_tile_task[(size_t)(st.tmap_off + b)];
+                if (ti < 0 || ti >= st.count) return bad("solve tile table entry of step", (int64_t)i);
+            }
+        } else {
+            if (st.first + st.count > (int64_t)sc.gemm.size()) return bad("gemm step range", (int64_t)i);
+            if (st.tmap_off < 0 || st.tmap_off + st.ntiles > (int64_t)sc.gemm_tile_tab.size()) return bad("gemm step tiles", (int64_t)i);
+            if (!check_tile_table(sc, st)) return bad("tile table of step", (int64_t)i);
+        }
+    }
+    for (size_t i = 0; i < sc.bcasts.size(); i++) {
+        const BcastPoint &b = sc.bcasts[i];
+        if (b.lo < 0 || b.count <= 0 || b.lo + b.count > xs || b.step < 0 || b.step > (int64_t)sc.steps.size() || b.root < 0)
+            return bad("broadcast", (int64_t)i);
+    }
+    if (!ss) return "";
+    for (size_t i = 0; i < ss->groups.size(); i++) {
+        const SolveGroupTask &g = ss->groups[i];
+        if (g.ncols <= 0 || g.ncols > SOLVE_GROUP * NB || g.lda < g.ncols) return bad("solve group shape", (int64_t)i);
+        if (g.a_off < 0 || last(g.a_off, g.ncols, g.ncols, g.lda) >= xs) return bad("solve group L", (int64_t)i);
+        if (g.x0 < 0 || (int64_t)g.x0 + g.ncols > S.n) return bad("solve group rows of X", (int64_t)i);
+        for (int b = 0; b * NB < g.ncols; b++) {
+            const int64_t nb = std::min<int64_t>(NB, g.ncols - b * NB);
+            if (g.dinv_off[b] < 0 || g.dinv_off[b] + nb * nb > ds) return bad("solve group Dinv", (int64_t)i);
+        }
+    }
+    for (size_t i = 0; i < ss->utasks.size(); i++) {
+        const PotrfTask &t = ss->utasks[i];
+        if (t.nb <= 0 || t.nb > NB || t.urow0 < t.col0 + t.nb || t.urow0 > t.lda) return bad("solve update task shape", (int64_t)i);
+        if (t.a_off < 0 || last(t.a_off, (int64_t)t.lda - t.col0, t.nb, t.lda) >= xs) return bad("solve update task L", (int64_t)i);
+        if (t.ls_off < 0 || t.ls_off + t.lda > ssz || (int64_t)t.k1 + t.col0 + t.nb > S.n) return bad("solve update task rows", (int64_t)i);
+    }
+    for (size_t i = 0; i < ss->steps.size(); i++) {
+        const SolveStep &st = ss->steps[i];
+        if (st.gfirst < 0 || st.gfirst + st.gcount > (int64_t)ss->groups.size()) return bad("solve step groups", (int64_t)i);
+        if (st.ufirst < 0 || st.ufirst + st.ucount > (int64_t)ss->utasks.size()) return bad("solve step update tasks", (int64_t)i);
+        if (st.tmap_off < 0 || st.tmap_off + st.stiles > (int64_t)ss->tile_task.size()) return bad("solve step tiles", (int64_t)i);
+        if (st.maxblk < 1 || st.maxblk > SOLVE_GROUP) return bad("solve step maxblk", (int64_t)i);
+        int64_t tiles = 0;
+        for (int64_t u = 0; u < st.ucount; u++) {
+            const PotrfTask &t = ss->utasks[(size_t)(st.ufirst + u)];
+            if (t.stile0 != tiles) return bad("solve step tile prefix", (int64_t)i);
+            tiles += ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+        }
+        if (tiles != st.stiles) return bad("solve step tile count", (int64_t)i);
+        for (int64_t b = 0; b < st.stiles; b++) {
+            const int32_t ti = ss->tile_task[(size_t)(st.tmap_off + b)];
+            if (ti < 0 || ti >= st.ucount) return bad("solve step tile entry", (int64_t)i);
+        }
+        for (int which = 0; which < 2; which++) {
+            const std::vector<SolveRange> &rg = which ? ss->ranges_mma : ss->ranges;
+            const int64_t r0 = which ? st.rmfirst : st.rfirst, rn = which ? st.rmcount : st.rcount;
+            if (r0 < 0 || r0 + rn > (int64_t)rg.size()) return bad("solve step runs", (int64_t)i);
+            int64_t covered = 0;
+            for (int64_t k = r0; k < r0 + rn; k++) {
+                const SolveRange &e = rg[(size_t)k];
+                if (e.task < 0 || e.task >= st.ucount || e.tile0 < 0 || e.ntiles <= 0) return bad("solve run", k);
+                const PotrfTask &t = ss->utasks[(size_t)(st.ufirst + e.task)];
+                const int64_t nt = ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                if (e.tile0 + e.ntiles > nt) return bad("solve run tiles", k);
+                covered += e.ntiles;
+            }
+            if (covered != st.stiles) return bad("solve step run coverage", (int64_t)i);
+        }
+    }
+    return "";
+}
+
 }  // namespace mi355

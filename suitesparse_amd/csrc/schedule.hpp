@@ -200,6 +200,12 @@ Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);
 
+// Every task of the schedule (and, when given, of its solve work lists) against the extents of the arrays the
+// kernels index with it: Lx (xsize entries), Dinv, the relative maps, Ls, X (n rows) and the tables themselves.
+// "" if fine, else what is wrong.  The engine runs it before a schedule reaches the device: a task that points
+// outside its arrays is a GPU memory fault, and that takes the machine down, not just the process.
+std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss = nullptr);
+
 // true if the table of step st lists every valid tile of every task of the step exactly once
 bool check_tile_table(const Schedule &sc, const Step &st);
 

@@ -422,4 +422,31 @@ int emu_super_solve_grouped(int lower, int mma, int64_t n, int64_t nsuper, const
     }
     return 0;
 }
+
+// check_schedule_bounds of the schedules one rank of a partition uploads (full, own subtrees, top, distributed top)
+// and of their solve work lists; returns 0 or the 1-based index of the first schedule that fails (message -> msg)
+int emu_validate_partition(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                           const int64_t *Ls, int64_t ssize, int64_t xsize, int cplx, const int8_t *local_mask,
+                           const int8_t *top_mask, int rank, int world, char *msg, int msglen)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls; S.cplx = cplx != 0;
+    Schedule full, loc, top, dst;
+    build_schedule(S, nsuper, 0, full);
+    build_schedule(S, nsuper, 0, loc, local_mask);
+    build_schedule(S, nsuper, 0, top, top_mask, loc.dinv_size);
+    DistTop dt; dt.rank = rank; dt.world = world;
+    build_schedule(S, nsuper, 0, dst, top_mask, loc.dinv_size, &dt);
+    // the engine sizes Dinv by the full schedule: the masked ones must fit inside
+    if (top.dinv_size > full.dinv_size || dst.dinv_size != top.dinv_size) { snprintf(msg, msglen, "Dinv slots do not fit"); return 9; }
+    Schedule *all[4] = {&full, &loc, &top, &dst};
+    for (int k = 0; k < 4; k++) {
+        SolveSchedule ss; build_solve_groups(*all[k], ss);
+        Schedule tmp = *all[k];
+        tmp.dinv_size = full.dinv_size;              // extents of the device buffer
+        std::string e = check_schedule_bounds(S, tmp, k < 3 ? &ss : nullptr);
+        if (!e.empty()) { snprintf(msg, msglen, "%s", e.c_str()); return k + 1; }
+    }
+    return 0;
+}
 }

@@ -189,6 +189,25 @@ def test_phases_with_simulated_ranks_match_oracle(kind, size, world):
                 assert relerr(f.Lx[a:b], Lo[a:b]) < 1e-11, (r, s)
 
 
+@pytest.mark.parametrize("kind,size,world", [("lap3d", 30, 4), ("lap3d", 24, 3), ("helm", 14, 2), ("lap2d", 120, 8)])
+def test_every_task_of_a_partition_stays_inside_its_arrays(kind, size, world):
+    """check_schedule_bounds (what the engine runs before any schedule reaches the device) on the four schedules
+    of every rank -- whole factor, own subtrees, top, owner-computes top -- and on their solve work lists"""
+    from suitesparse_amd import problems, symbolic
+    p = {"lap3d": problems.laplacian_3d, "lap2d": problems.laplacian_2d, "helm": problems.helmholtz_3d}[kind](size)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
+    emu = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    emu.emu_validate_partition.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, C.c_int,
+                                           i8p, i8p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    owner = multigpu.partition(sym, world)["owner"]
+    for r in range(world):
+        msg = C.create_string_buffer(300)
+        rc = emu.emu_validate_partition(sym["n"], sym["nsuper"], sym["Super"], sym["Lpi"], sym["Lpx"], sym["Ls"],
+                                        len(sym["Ls"]), sym["xsize"], int(kind == "helm"),
+                                        (owner == r).astype(np.int8), (owner < 0).astype(np.int8), r, world, msg, 300)
+        assert rc == 0, (r, rc, msg.value.decode())
+
+
 def run_distributed_lockstep(runners, facs):
     """the owner-computes top with simulated ranks: every rank runs segment k, then block k travels"""
     plans = [rn.plan for rn in runners]
