@@ -30,6 +30,8 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
 {
     if (init) std::fill(Lx, Lx + S.xsize, 0.0);
     info.assign(S.nsuper + 2, 0);
+    // what the engine checks before a schedule reaches the device must hold for every schedule run here
+    if (!check_schedule_bounds(S, sc).empty()) { info[S.nsuper + 1] = -1; return; }
     if (!keep_dinv) Dinv.assign(sc.dinv_size + 1, 0.0);
     if (step1 < 0) step1 = (int64_t)sc.steps.size();
     for (int64_t k = 0; init && k < ncols_asm; k++) {
@@ -336,6 +338,7 @@ int emu_super_solve_grouped(int lower, int mma, int64_t n, int64_t nsuper, const
     S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
     Schedule sc; build_schedule(S, nsuper, 0, sc);
     SolveSchedule ss; build_solve_groups(sc, ss);
+    if (!check_schedule_bounds(S, sc, &ss).empty()) return -40;
     auto group_part = [&](const SolveStep &st) {
         for (int64_t gi = st.gfirst; gi < st.gfirst + st.gcount; gi++) {
             const SolveGroupTask &g = ss.groups[(size_t)gi];
