@@ -141,9 +141,8 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
     Schedule &S = D.sched;
     {
         // no task may point outside the arrays the kernels index with it (a GPU memory fault takes the machine down)
-        Schedule ext = S;                              // Dinv is sized by the full schedule (all blocks)
-        ext.dinv_size = std::max<int64_t>(S.dinv_size, F->full.sched.dinv_size);
-        const std::string bad = check_schedule_bounds(F->sym, ext);
+        // (Dinv is sized by the full schedule: all blocks)
+        const std::string bad = check_schedule_bounds(F->sym, S, nullptr, std::max<int64_t>(S.dinv_size, F->full.sched.dinv_size));
         if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: schedule rejected before upload: " + bad);
     }
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
@@ -934,9 +933,9 @@ static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
     if (DS.solve_groups_ready) return MI355_OK;
     build_solve_groups(DS.sched, DS.ssched);
     {
-        Schedule ext;                                  // tasks already checked at upload: only the solve work lists here
-        ext.dinv_size = std::max<int64_t>(DS.sched.dinv_size, F->full.sched.dinv_size);
-        const std::string bad = check_schedule_bounds(F->sym, ext, &DS.ssched);
+        const Schedule none;                           // tasks already checked at upload: only the solve work lists here
+        const std::string bad = check_schedule_bounds(F->sym, none, &DS.ssched,
+                                                      std::max<int64_t>(DS.sched.dinv_size, F->full.sched.dinv_size));
         if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: solve work lists rejected before upload: " + bad);
     }
     HIP_TRY(DS.sgroups.upload(DS.ssched.groups.data(), DS.ssched.groups.size(), F->stream));

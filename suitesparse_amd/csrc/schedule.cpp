@@ -588,10 +588,11 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
     }
 }
 
-std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss)
+std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss, int64_t dinv_extent)
 {
     char buf[256];
-    const int64_t xs = S.xsize, ds = sc.dinv_size, rs = sc.relmap_size, ssz = S.Lpi ? S.Lpi[S.nsuper] : 0;
+    const int64_t xs = S.xsize, ds = dinv_extent >= 0 ? dinv_extent : sc.dinv_size, rs = sc.relmap_size;
+    const int64_t ssz = S.Lpi ? S.Lpi[S.nsuper] : 0;
     auto bad = [&](const char *what, int64_t i) { snprintf(buf, sizeof buf, "%s %lld out of bounds", what, (long long)i); return std::string(buf); };
     // last entry a column-major block (rows x cols, ld) reaches, from off
     auto last = [](int64_t off, int64_t rows, int64_t cols, int64_t ld) { return off + (rows - 1) + (cols - 1) * ld; };
@@ -633,7 +634,14 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         } else {
             if (st.first + st.count > (int64_t)sc.gemm.size()) return bad("gemm step range", (int64_t)i);
             if (st.tmap_off < 0 || st.tmap_off + st.ntiles > (int64_t)sc.gemm_tile_tab.size()) return bad("gemm step tiles", (int64_t)i);
-            if (!check_tile_table(sc, st)) return bad("tile table of step", (int64_t)i);
+            for (int64_t b = 0; b < st.ntiles; b++) {      // every workgroup's (task, tile) inside its task
+                const Schedule::TileEntry e = sc.gemm_tile_tab[(size_t)(st.tmap_off + b)];
+                if (e.task < 0 || e.task >= st.count) return bad("tile table entry of step", (int64_t)i);
+                const GemmTask &t = sc.gemm[(size_t)(st.first + e.task)];
+                const int tr = tile_rows(t.big), tc = tile_cols(t.big);
+                if ((int64_t)(e.tmtn & 0xffff) * tr >= t.M || (int64_t)(e.tmtn >> 16) * tc >= t.N)
+                    return bad("tile of step", (int64_t)i);
+            }
         }
     }
     for (size_t i = 0; i < sc.bcasts.size(); i++) {

@@ -204,7 +204,8 @@ void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedul
 // kernels index with it: Lx (xsize entries), Dinv, the relative maps, Ls, X (n rows) and the tables themselves.
 // "" if fine, else what is wrong.  The engine runs it before a schedule reaches the device: a task that points
 // outside its arrays is a GPU memory fault, and that takes the machine down, not just the process.
-std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss = nullptr);
+std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss = nullptr,
+                                  int64_t dinv_extent = -1 /* entries of the Dinv buffer; default: sc.dinv_size */);
 
 // true if the table of step st lists every valid tile of every task of the step exactly once
 bool check_tile_table(const Schedule &sc, const Step &st);

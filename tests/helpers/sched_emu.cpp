@@ -445,9 +445,7 @@ int emu_validate_partition(int64_t n, int64_t nsuper, const int64_t *Super, cons
     Schedule *all[4] = {&full, &loc, &top, &dst};
     for (int k = 0; k < 4; k++) {
         SolveSchedule ss; build_solve_groups(*all[k], ss);
-        Schedule tmp = *all[k];
-        tmp.dinv_size = full.dinv_size;              // extents of the device buffer
-        std::string e = check_schedule_bounds(S, tmp, k < 3 ? &ss : nullptr);
+        std::string e = check_schedule_bounds(S, *all[k], k < 3 ? &ss : nullptr, full.dinv_size /* the device buffer */);
         if (!e.empty()) { snprintf(msg, msglen, "%s", e.c_str()); return k + 1; }
     }
     return 0;
