@@ -131,7 +131,9 @@ int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *
  *      [caller sums the top panels' Lx ranges over the ranks: RCCL all-reduce]
  *      phase 1: factorize the top supernodes.
  *      *first_bad = first supernode whose pivot failed in that phase (-1: none), *info = LAPACK
- *      info inside it.  The repeat-supernode protocol is not replayed on this path. */
+ *      info inside it.  A phase sees only its own supernodes, so on a failure the caller replays the
+ *      reference's protocol (smallest failing supernode, zero tail, refactorized leading columns) with
+ *      mi355_factor_numeric, which ignores the partition (suitesparse_amd/multigpu.py, _replay). */
 int mi355_factor_set_partition(mi355_factor *handle, const int8_t *local_mask,
                                const int8_t *top_mask, const int8_t *asm_mask);
 int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,

@@ -187,11 +187,25 @@ class PartitionedFactor:
             self.status, self.minor = 1, int(self.Super[bad]) + info - 1
         return bad
 
-    def numeric(self, beta=0.0):
+    def _replay(self, beta, quick):
+        """Not positive definite: the reference stops at the SMALLEST failing supernode, zeroes everything after
+        the failing column and refactorizes the leading columns of that supernode
+        (t_cholmod_super_numeric_worker.c:1084-1146).  A phase only sees the supernodes it processes (a subtree with
+        a larger index may fail in phase 0 while a top supernode with a smaller index would fail later), so the
+        rare failing case is replayed by every rank on its own with the undistributed schedule
+        (mi355_factor_numeric ignores the partition): same L->minor, status and zero pattern as the reference."""
+        full = getattr(self.f, "numeric", None)
+        if full is None:
+            return self.status
+        self.status = int(full(beta, quick))
+        self.minor = int(self.f.minor)
+        return self.status
+
+    def numeric(self, beta=0.0, quick_return_if_not_posdef=False):
         self.status, self.minor = 0, self.n
         bad, info = self.f.numeric_phase(0, beta)
         if self._agree(bad, info) >= 0:
-            return self.status
+            return self._replay(beta, quick_return_if_not_posdef)
         if self.world > 1 and self.tensors:
             self.allreduce(self.tensors)
         if self.dist:
@@ -201,6 +215,8 @@ class PartitionedFactor:
         else:
             bad, info = self.f.numeric_phase(1, beta)
             self._agree(bad, info)
+        if self.status != 0:
+            return self._replay(beta, quick_return_if_not_posdef)
         return self.status
 
     # ---- solves: X is a torch tensor holding n x nrhs entries column-major (leading dimension n), the

@@ -58,6 +58,20 @@ class EmuFactor:
             self.dinv_local_end = int(end.value)
         return int(bad.value), int(info.value)
 
+    def numeric(self, beta=0.0, quick=False):
+        """mi355_factor_numeric: the whole factor with the undistributed schedule, incl. the not-posdef protocol"""
+        g = self.g
+        self.E.emu_super_numeric.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p,
+                                             i64p, f64p, C.c_double, C.c_int, f64p, f64p, i64p, C.POINTER(C.c_int), i64p]
+        minor, st, stats = np.zeros(1, dtype=np.int64), C.c_int(0), np.zeros(8, dtype=np.int64)
+        D = np.zeros(self.Dinv.size + 1)
+        rc = self.E.emu_super_numeric(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"],
+                                      g["xsize"], g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64),
+                                      beta, int(bool(quick)), self.Lx, D, minor, C.byref(st), stats)
+        assert rc == 0
+        self.minor = int(minor[0])
+        return st.value
+
     def set_top_distribution(self, rank, world):
         g = self.g
         self.rank, self.world = rank, world
@@ -206,6 +220,58 @@ def test_every_task_of_a_partition_stays_inside_its_arrays(kind, size, world):
                                         len(sym["Ls"]), sym["xsize"], int(kind == "helm"),
                                         (owner == r).astype(np.int8), (owner < 0).astype(np.int8), r, world, msg, 300)
         assert rc == 0, (r, rc, msg.value.decode())
+
+
+@pytest.mark.parametrize("where", ["subtree", "top", "top_and_later_subtree"])
+@pytest.mark.parametrize("quick", [False, True])
+def test_not_posdef_on_a_partition_replays_the_reference_protocol(where, quick):
+    """a bad pivot on N ranks: status, L->minor AND the factor (zero tail, refactorized leading columns of the
+    failing supernode, t_cholmod_super_numeric_worker.c:1084-1146) are the oracle's on every rank -- also when
+    a subtree with a larger index fails in phase 0 and a top supernode with a smaller index fails as well"""
+    from oracle import port
+    g = dict(problem("lap3d", 12))
+    world = 3
+    owner = multigpu.partition(g, world)["owner"]
+    Super, Sp = g["Super"], g["Sp"]
+    tops = np.nonzero(owner < 0)[0]
+    assert tops.size >= 2
+    s_top = int(tops[0])                                  # the lowest top supernode
+    later = [s for s in range(s_top + 1, g["nsuper"]) if owner[s] >= 0]
+    Sx = g["Sx"].copy()
+
+    def spoil(s, col_in):
+        col = int(Super[s]) + min(col_in, int(Super[s + 1] - Super[s]) - 1)
+        Sx[Sp[col]] = -5.0                               # the diagonal entry comes first in a column of tril(S)
+    if where == "subtree":
+        spoil(int(np.nonzero(owner == 1)[0][3]), 0)
+    elif where == "top":
+        spoil(s_top, 2)
+    else:
+        if not later:
+            pytest.skip("no subtree after the first top supernode in this partition")
+        spoil(s_top, 2); spoil(later[-1], 0)
+    g["Sx"] = Sx
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"], quick_return=quick)
+    assert so == 1
+    facs = [EmuFactor(g) for _ in range(world)]
+    # sequential simulation: the ranks cannot exchange (bad, info) mid-call, so drive the phases by hand as
+    # PartitionedFactor.numeric does, with the agreement computed over all ranks
+    runners = [multigpu.PartitionedFactor(f, g, r, world, allreduce=lambda t: None, distribute_top=False)
+               for r, f in enumerate(facs)]
+    res0 = [rn.f.numeric_phase(0) for rn in runners]
+    bad0 = min([b for b, _ in res0 if b >= 0], default=-1)
+    if bad0 < 0:
+        for lo, hi in runners[0].part["top_ranges"]:
+            tot = sum(f.Lx[lo:hi] for f in facs)
+            for f in facs:
+                f.Lx[lo:hi] = tot
+        res1 = [rn.f.numeric_phase(1) for rn in runners]
+        assert min([b for b, _ in res1 if b >= 0], default=-1) >= 0
+    for rn in runners:
+        st = rn._replay(0.0, quick)
+        assert (st, rn.minor) == (so, mo)
+        assert relerr(rn.f.Lx, Lo) < 1e-11
+        assert ((rn.f.Lx == 0) == (Lo == 0)).all()
 
 
 def run_distributed_lockstep(runners, facs):
