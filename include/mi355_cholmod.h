@@ -89,6 +89,19 @@ int mi355_factor_set_matrix_zomplex(mi355_factor *handle, const int64_t *Ap, con
 int mi355_factor_set_matrix_perm(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
                                  const int64_t *Anz, const double *Ax, const int64_t *Perm);
 
+/* stype == 0 (cholmod_super_numeric(A, F, beta, L), CHOLMOD/Supernodal/cholmod_super_numeric.c:135-154): the pair
+ * A (n x ncol; Ap has ncol+1 entries, row indices < n) and F = A' or A(:,f)' (ncol x n; Fp has n+1 entries, row
+ * indices < ncol; the conjugate transpose for complex values) exactly as cholmod_factorize builds them
+ * (CHOLMOD/Cholesky/cholmod_factorize.c:201-210,240-250).  The matrix factorized is A*F + beta*I: the assembly kernel
+ * accumulates column k as the sum over F(j,k) of A(:,j)*F(j,k), rows i >= k (worker
+ * t_cholmod_super_numeric_worker.c:471-506); A*F is never formed.  Anz / Fnz: NULL when packed.  Az, Fz: both NULL
+ * (real, or complex interleaved in Ax / Fx) or both given (zomplex, complex L). */
+int mi355_factor_set_matrix_unsym(mi355_factor *handle, int64_t ncol,
+                                  const int64_t *Ap, const int64_t *Ai, const int64_t *Anz,
+                                  const double *Ax, const double *Az,
+                                  const int64_t *Fp, const int64_t *Fi, const int64_t *Fnz,
+                                  const double *Fx, const double *Fz);
+
 /* Factorize the staged matrix: Lx (device) <- chol(S + beta*I).  *status receives
  * CHOLMOD_OK or CHOLMOD_NOT_POSDEF and *minor the reference's L->minor (n if positive
  * definite), with the reference's zeroing/repeat-supernode semantics
@@ -114,7 +127,7 @@ int mi355_factor_rcond(mi355_factor *handle, double *rcond);
 int mi355_factor_to_simplicial(mi355_factor *handle, int to_ll, int64_t *Lp, int64_t *Li, int64_t *Lnz,
                                double *Lx, int64_t *lnz);
 
-/* One call = cholmod_super_numeric's numeric part for (int64, double, real, stype<0):
+/* One call = cholmod_super_numeric's numeric part for (int64, double, stype<0; stype == 0: the split form above):
  * set_matrix + numeric + get_Lx on an existing handle (create it once per analyze). */
 int mi355_super_numeric(mi355_factor *handle, const int64_t *Ap, const int64_t *Ai,
                         const int64_t *Anz, const double *Ax, double beta_re,

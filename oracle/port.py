@@ -20,6 +20,11 @@ def lib():
                                            C.c_int64, C.c_int64, i64p, i64p, C.c_void_p, f64p,
                                            C.c_double, C.c_int, f64p, i64p]
         L.oracle_super_numeric.restype = C.c_int
+        L.oracle_super_numeric_f.argtypes = [C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p,
+                                             C.c_int64, C.c_int64, i64p, i64p, C.c_void_p, f64p,
+                                             i64p, i64p, C.c_void_p, f64p,
+                                             C.c_double, C.c_int, f64p, i64p]
+        L.oracle_super_numeric_f.restype = C.c_int
         for f in (L.oracle_super_lsolve, L.oracle_super_ltsolve):
             f.argtypes = [C.c_int, C.c_int64, i64p, i64p, i64p, i64p, f64p, C.c_int64, f64p, C.c_int64]
             f.restype = C.c_int
@@ -56,6 +61,25 @@ def super_numeric(sym, Sp, Si, Sx, beta=0.0, quick_return=False):
                                     float(beta), int(bool(quick_return)), Lx, minor)
     if st < 0:
         raise RuntimeError(f"oracle_super_numeric failed: {st}")
+    return st, int(minor[0]), (Lx.view(np.complex128) if E == 2 else Lx)
+
+
+def super_numeric_unsym(sym, Ap, Ai, Ax, Fp, Fi, Fx, beta=0.0, quick_return=False):
+    """stype == 0: chol(A*F + beta*I), A n x ncol, F = A' (conjugate transpose) ncol x n, both packed CSC
+    (cholmod_super_numeric(A, F, ...), worker :471-506).  Returns (status, minor, Lx)."""
+    Axf, E = _flat(Ax)
+    Fxf, E2 = _flat(Fx)
+    assert E == E2
+    pad = lambda a: a if a.size else np.zeros(2, dtype=a.dtype)
+    Lx = np.zeros(max(int(sym["xsize"]), 1) * E)
+    minor = np.zeros(1, dtype=np.int64)
+    i64 = lambda a: pad(np.ascontiguousarray(a, dtype=np.int64))
+    st = lib().oracle_super_numeric_f(E, int(sym["n"]), int(sym["nsuper"]), i64(sym["Super"]), i64(sym["Lpi"]),
+                                      i64(sym["Lpx"]), i64(sym["Ls"]), int(sym["xsize"]), int(sym["maxcsize"]),
+                                      i64(Ap), i64(Ai), None, pad(Axf), i64(Fp), i64(Fi), None, pad(Fxf),
+                                      float(beta), int(bool(quick_return)), Lx, minor)
+    if st < 0:
+        raise RuntimeError(f"oracle_super_numeric_f failed: {st}")
     return st, int(minor[0]), (Lx.view(np.complex128) if E == 2 else Lx)
 
 

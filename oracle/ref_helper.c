@@ -21,7 +21,8 @@ typedef struct
 {
     cholmod_common cm ;
     cholmod_sparse *A ;     // user matrix (any stype)
-    cholmod_sparse *S ;     // tril (P A P'), what super_numeric receives
+    cholmod_sparse *S ;     // tril (P A P'), what super_numeric receives (stype == 0: A(p,f))
+    cholmod_sparse *F ;     // stype == 0 only: F = A(p,f)', the second argument of super_numeric
     cholmod_factor *L ;
     double t_analyze, t_factor, t_solve ;
     int last_status ;
@@ -47,6 +48,7 @@ void ref_free (void *hv)
     ref_ctx *h = hv ;
     if (!h) return ;
     if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    cholmod_l_free_sparse (&h->F, &h->cm) ;
     cholmod_l_free_sparse (&h->A, &h->cm) ;
     cholmod_l_free_factor (&h->L, &h->cm) ;
     cholmod_l_finish (&h->cm) ;
@@ -69,6 +71,24 @@ int ref_load_matrix (void *hv, int64_t n, const int64_t *Ap, const int64_t *Ai,
         /*packed*/ 1, stype, xtype + CHOLMOD_DOUBLE, &h->cm) ;
     if (!h->A) return -1 ;
     memcpy (h->A->p, Ap, (n+1) * sizeof (int64_t)) ;
+    memcpy (h->A->i, Ai, nz * sizeof (int64_t)) ;
+    memcpy (h->A->x, Ax, nz * sizeof (double) * (xtype == CHOLMOD_COMPLEX ? 2 : 1)) ;
+    return 0 ;
+}
+
+// unsymmetric n x ncol matrix (stype 0): the reference then factorizes A*A' (cholmod_factorize.c:201-210,240-250)
+int ref_load_matrix_rect (void *hv, int64_t nrow, int64_t ncol, const int64_t *Ap, const int64_t *Ai,
+    const double *Ax, int xtype)
+{
+    ref_ctx *h = hv ;
+    if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
+    h->S = NULL ;
+    cholmod_l_free_sparse (&h->F, &h->cm) ;
+    cholmod_l_free_sparse (&h->A, &h->cm) ;
+    int64_t nz = Ap [ncol] ;
+    h->A = cholmod_l_allocate_sparse (nrow, ncol, nz > 0 ? nz : 1, 1, 1, 0, xtype + CHOLMOD_DOUBLE, &h->cm) ;
+    if (!h->A) return -1 ;
+    memcpy (h->A->p, Ap, (ncol+1) * sizeof (int64_t)) ;
     memcpy (h->A->i, Ai, nz * sizeof (int64_t)) ;
     memcpy (h->A->x, Ax, nz * sizeof (double) * (xtype == CHOLMOD_COMPLEX ? 2 : 1)) ;
     return 0 ;
@@ -200,7 +220,23 @@ int64_t ref_permute (void *hv)
     cholmod_factor *L = h->L ;
     if (h->S && h->S != h->A) cholmod_l_free_sparse (&h->S, &h->cm) ;
     h->S = NULL ;
-    if (A->stype == 0) return -1 ;
+    cholmod_l_free_sparse (&h->F, &h->cm) ;
+    if (A->stype == 0)
+    {
+        // F = A(p,:)' ; S = F'  (cholmod_factorize.c:201-210 natural, :240-250 permuted; no fset)
+        if (L->ordering == CHOLMOD_NATURAL)
+        {
+            h->F = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, &h->cm) ;
+            h->S = A ;
+        }
+        else
+        {
+            h->F = cholmod_l_ptranspose (A, 2, L->Perm, NULL, 0, &h->cm) ;
+            h->S = h->F ? cholmod_l_ptranspose (h->F, 2, NULL, NULL, 0, &h->cm) : NULL ;
+        }
+        if (!h->S || !h->F) return -2 ;
+        return cholmod_l_nnz (h->S, &h->cm) ;
+    }
     if (L->ordering == CHOLMOD_NATURAL)
     {
         if (A->stype > 0) { A1 = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, &h->cm) ; h->S = A1 ; }
@@ -231,6 +267,24 @@ void ref_get_S (void *hv, int64_t *Sp, int64_t *Si, double *Sx)
     h->A = Asave ;
 }
 
+// F of the last ref_permute of an unsymmetric matrix (ncol x n); sizes via ref_F_info: nrow, ncol, nnz
+void ref_F_info (void *hv, int64_t *iout)
+{
+    ref_ctx *h = hv ;
+    iout [0] = h->F ? (int64_t) h->F->nrow : 0 ;
+    iout [1] = h->F ? (int64_t) h->F->ncol : 0 ;
+    iout [2] = h->F ? cholmod_l_nnz (h->F, &h->cm) : 0 ;
+}
+
+void ref_get_F (void *hv, int64_t *Fp, int64_t *Fi, double *Fx)
+{
+    ref_ctx *h = hv ;
+    cholmod_sparse *Asave = h->A ;
+    h->A = h->F ;
+    ref_get_matrix (hv, Fp, Fi, Fx) ;
+    h->A = Asave ;
+}
+
 // numeric factorization through the reference CPU worker; returns Common->status
 // (0 OK, 1 NOT_POSDEF, <0 error).  Needs ref_permute first.
 int ref_factorize (void *hv, double beta_re, int quick_return_if_not_posdef)
@@ -239,7 +293,7 @@ int ref_factorize (void *hv, double beta_re, int quick_return_if_not_posdef)
     double beta [2] = { beta_re, 0 } ;
     h->cm.quick_return_if_not_posdef = quick_return_if_not_posdef ;
     double t = SuiteSparse_time ( ) ;
-    int ok = cholmod_l_super_numeric (h->S, NULL, beta, h->L, &h->cm) ;
+    int ok = cholmod_l_super_numeric (h->S, h->S->stype == 0 ? h->F : NULL, beta, h->L, &h->cm) ;
     h->t_factor = SuiteSparse_time ( ) - t ;
     h->last_status = h->cm.status ;
     return ok ? h->cm.status : (h->cm.status < 0 ? h->cm.status : -99) ;

@@ -36,6 +36,9 @@ def lib():
         L.ref_set_nthreads.argtypes = [C.c_void_p, C.c_int]
         L.ref_load_matrix.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, f64p, C.c_int, C.c_int]
         L.ref_read_matrix.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_load_matrix_rect.argtypes = [C.c_void_p, C.c_int64, C.c_int64, i64p, i64p, f64p, C.c_int]
+        L.ref_F_info.argtypes = [C.c_void_p, i64p]
+        L.ref_get_F.argtypes = [C.c_void_p, i64p, i64p, f64p]
         L.ref_matrix_info.argtypes = [C.c_void_p, i64p]
         L.ref_get_matrix.argtypes = [C.c_void_p, i64p, i64p, f64p]
         L.ref_analyze.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -92,6 +95,22 @@ class RefCholmod:
         if rc != 0:
             raise RuntimeError("ref_load_matrix failed")
         self.n = n
+        self.xtype = 2 if cplx else 1
+
+    def load_rect(self, nrow, ncol, Ap, Ai, Ax):
+        """unsymmetric nrow x ncol matrix (stype 0): analyze/factorize then work on A*A'"""
+        Ap = np.ascontiguousarray(Ap, dtype=np.int64)
+        Ai = np.ascontiguousarray(Ai, dtype=np.int64)
+        cplx = np.iscomplexobj(Ax)
+        Axf = np.ascontiguousarray(Ax, dtype=np.complex128).view(np.float64) if cplx \
+            else np.ascontiguousarray(Ax, dtype=np.float64)
+        if Axf.size == 0:
+            Axf = np.zeros(2)
+        if Ai.size == 0:
+            Ai = np.zeros(1, dtype=np.int64)
+        if self.L.ref_load_matrix_rect(self.h, nrow, ncol, Ap, Ai, Axf, 2 if cplx else 1) != 0:
+            raise RuntimeError("ref_load_matrix_rect failed")
+        self.n = nrow
         self.xtype = 2 if cplx else 1
 
     def read(self, path):
@@ -156,13 +175,31 @@ class RefCholmod:
                     maxesize=inf["maxesize"], Perm=Perm, ColCount=ColCount, Super=Super,
                     Lpi=Lpi, Lpx=Lpx, Ls=Ls[:ss])
 
+    def permuted_unsym(self):
+        """stype == 0: (S, F) = (A(p,:), A(p,:)') exactly as cholmod_factorize hands them to super_numeric
+        (cholmod_factorize.c:201-210,240-250).  Returns ((Sp, Si, Sx), (Fp, Fi, Fx)); S is n x ncol, F ncol x n."""
+        S = self.permuted()
+        info = np.zeros(8, dtype=np.int64)
+        self.L.ref_F_info(self.h, info)
+        frow, fcol, fnz = (int(v) for v in info[:3])
+        assert fcol == self.n
+        E = 2 if self.xtype == 2 else 1
+        Fp = np.zeros(fcol + 1, dtype=np.int64)
+        Fi = np.zeros(max(fnz, 1), dtype=np.int64)
+        Fx = np.zeros(max(fnz, 1) * E)
+        self.L.ref_get_F(self.h, Fp, Fi, Fx)
+        Fi, Fx = Fi[:fnz], Fx[:fnz * E]
+        return S, (Fp, Fi, Fx.view(np.complex128) if E == 2 else Fx)
+
     def permuted(self):
         """S = tril(P A P') exactly as cholmod_factorize builds it."""
         nnz = self.L.ref_permute(self.h)
         if nnz < 0:
             raise RuntimeError("ref_permute failed")
         E = 2 if self.xtype == 2 else 1
-        Sp = np.zeros(self.n + 1, dtype=np.int64)
+        info = np.zeros(8, dtype=np.int64)
+        self.L.ref_matrix_info(self.h, info)
+        Sp = np.zeros((int(info[4]) if int(info[3]) == 0 else self.n) + 1, dtype=np.int64)
         Si = np.zeros(max(nnz, 1), dtype=np.int64)
         Sx = np.zeros(max(nnz, 1) * E)
         self.L.ref_get_S(self.h, Sp, Si, Sx)

@@ -204,13 +204,16 @@ static void x_trsm_rlcn (int E, Int m, Int n, const double *A, Int lda, double *
 // values interleaved in Ax (a zomplex A must be interleaved by the caller, which is
 // what the zd_ instantiation does on the fly, t_cholmod_super_numeric_worker.c:69-83).
 // Lx (E*xsize doubles) is overwritten.  Returns ORACLE_OK / ORACLE_NOT_POSDEF / <0.
-int oracle_super_numeric
+// With F != NULL (stype == 0): A is n x ncol, F = A' or A(:,f)' is ncol x n (conjugate transpose for complex
+// values, cholmod_factorize.c:203-210,242-250), and the matrix factorized is A*F + beta*I (worker :471-506).
+int oracle_super_numeric_f
 (
     int E,                      // 1 real, 2 complex
     Int n, Int nsuper,
     const Int *Super, const Int *Lpi, const Int *Lpx, const Int *Ls,
     Int xsize, Int maxcsize,
     const Int *Ap, const Int *Ai, const Int *Anz, const double *Ax,
+    const Int *Fp, const Int *Fi, const Int *Fnz, const double *Fx,
     double beta_re, int quick_return_if_not_posdef,
     double *Lx, Int *minor_out
 )
@@ -257,8 +260,37 @@ int oracle_super_numeric
         // Map (:392-399)
         for (Int k = 0 ; k < nsrow ; k++) Map [Ls [psi + k]] = k ;
 
+        // copy A*F into the supernode (stype == 0, :471-506): column k = sum over j in F(:,k) of A(:,j)*F(j,k)
+        for (Int k = k1 ; Fp != NULL && k < k2 ; k++)
+        {
+            Int pf = Fp [k] ;
+            Int pfend = (Fnz == NULL) ? Fp [k+1] : pf + Fnz [k] ;
+            for ( ; pf < pfend ; pf++)
+            {
+                Int j = Fi [pf] ;
+                double fr = Fx [E*pf], fi = (E == 2) ? Fx [2*pf+1] : 0 ;
+                Int p = Ap [j] ;
+                Int pend = (Anz == NULL) ? Ap [j+1] : p + Anz [j] ;
+                for ( ; p < pend ; p++)
+                {
+                    Int i = Ai [p] ;
+                    if (i < k) continue ;
+                    Int imap = Map [i] ;
+                    if (imap < 0 || imap >= nsrow) continue ;
+                    Int q = imap + (psx + (k-k1)*nsrow) ;
+                    if (E == 1) Lx [q] += Ax [p] * fr ;
+                    else
+                    {
+                        // L_MULTADD: Lx [q] += Ax [p] * fjk (complex product, no conjugate)
+                        Lx [2*q]   += Ax [2*p] * fr - Ax [2*p+1] * fi ;
+                        Lx [2*q+1] += Ax [2*p+1] * fr + Ax [2*p] * fi ;
+                    }
+                }
+            }
+        }
+
         // copy A into the supernode (:438-470)
-        for (Int k = k1 ; k < k2 ; k++)
+        for (Int k = k1 ; Fp == NULL && k < k2 ; k++)
         {
             Int p = Ap [k] ;
             Int pend = (Anz == NULL) ? Ap [k+1] : p + Anz [k] ;
@@ -503,4 +535,19 @@ int oracle_super_ltsolve (int E, Int nsuper, const Int *Super, const Int *Lpi,
         }
     }
     return 0 ;
+}
+
+// stype < 0: A = tril (P A P'), F not used
+int oracle_super_numeric
+(
+    int E, Int n, Int nsuper,
+    const Int *Super, const Int *Lpi, const Int *Lpx, const Int *Ls,
+    Int xsize, Int maxcsize,
+    const Int *Ap, const Int *Ai, const Int *Anz, const double *Ax,
+    double beta_re, int quick_return_if_not_posdef,
+    double *Lx, Int *minor_out
+)
+{
+    return oracle_super_numeric_f (E, n, nsuper, Super, Lpi, Lpx, Ls, xsize, maxcsize, Ap, Ai, Anz, Ax,
+        NULL, NULL, NULL, NULL, beta_re, quick_return_if_not_posdef, Lx, minor_out) ;
 }

@@ -117,6 +117,10 @@ struct mi355_factor_s {
     bool have_A = false, A_unpacked = false;
     bool A_perm = false;        // the staged matrix is A itself; dIperm places it (mi355_factor_set_matrix_perm)
     DevBuf<int64_t> dIperm;
+    // stype == 0: the staged pair is (A, F) and the matrix factorized is A*F (mi355_factor_set_matrix_unsym)
+    bool A_unsym = false, F_unpacked = false;
+    DevBuf<int64_t> Fp, Fi, Fnz;
+    DevBuf<double> Fx;
     bool numeric_ok = false;    // a positive-definite factor is resident
     bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
     bool not_posdef = false;    // the last mi355_factor_numeric stopped at a bad pivot (L->minor < n)
@@ -229,7 +233,15 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     const bool cplx = F->E == 2;
     if (init && ncols_asm > 0) {
         const unsigned grid = (unsigned)((ncols_asm + 255) / 256);
-        if (F->A_perm) {
+        if (F->A_unsym) {
+            hipLaunchKernelGGL(cplx ? k_assemble_aat<2> : k_assemble_aat<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
+                               F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p,
+                               F->Fp.p, F->Fi.p, F->F_unpacked ? F->Fnz.p : (const int64_t *)nullptr, F->Fx.p,
+                               F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, smask);
+            if (beta != 0.0)
+                hipLaunchKernelGGL(cplx ? k_add_beta<2> : k_add_beta<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm, beta,
+                                   F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->Lx.p, smask);
+        } else if (F->A_perm) {
             hipLaunchKernelGGL(cplx ? k_assemble_perm<2> : k_assemble_perm<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
                                F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p, F->dIperm.p,
                                F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, smask);
@@ -441,6 +453,38 @@ int mi355_factor_free(mi355_factor *F)
     return MI355_OK;
 }
 
+// one cholmod_sparse (ncols columns, row indices below nrows; packed when nz == NULL; z != NULL: zomplex,
+// interleaved on the way in as the zd_ worker does on the fly, worker :69-83) into device buffers
+static int stage_csc(mi355_factor *F, int64_t ncols, int64_t nrows, const int64_t *p_, const int64_t *i_,
+                     const int64_t *nz_, const double *x_, const double *z_, DevBuf<int64_t> &dp, DevBuf<int64_t> &di,
+                     DevBuf<int64_t> &dnz, DevBuf<double> &dx, bool &unpacked)
+{
+    if (!p_ || !i_ || !x_) return fail(MI355_INVALID, "null matrix array");
+    // extent of i/x actually referenced
+    int64_t nzmax = 0;
+    for (int64_t k = 0; k < ncols; k++) {
+        const int64_t p = p_[k], pend = nz_ ? p + nz_[k] : p_[k + 1];
+        if (p < 0 || pend < p) return fail(MI355_INVALID, "matrix column pointers invalid");
+        nzmax = std::max(nzmax, pend);
+    }
+    if (!nz_) nzmax = std::max(nzmax, p_[ncols]);
+    for (int64_t p = 0; p < nzmax; p++)
+        if (i_[p] < 0 || i_[p] >= nrows) return fail(MI355_INVALID, "matrix row index out of range");
+    HIP_TRY(dp.upload(p_, (size_t)ncols + 1, F->stream));
+    HIP_TRY(di.upload(i_, (size_t)nzmax, F->stream));
+    if (F->E == 2 && z_) {
+        std::vector<double> z((size_t)nzmax * 2);
+        for (int64_t p = 0; p < nzmax; p++) { z[2 * p] = x_[p]; z[2 * p + 1] = z_[p]; }
+        HIP_TRY(dx.upload(z.data(), z.size(), F->stream));
+    } else {
+        if (F->E == 1 && z_) return fail(MI355_INVALID, "complex type mismatch: zomplex A with a real L");
+        HIP_TRY(dx.upload(x_, (size_t)nzmax * F->E, F->stream));
+    }
+    unpacked = (nz_ != nullptr);
+    if (nz_) HIP_TRY(dnz.upload(nz_, (size_t)ncols, F->stream));
+    return MI355_OK;
+}
+
 static int set_matrix_impl(mi355_factor *F, const int64_t *Ap, const int64_t *Ai,
                            const int64_t *Anz, const double *Ax, const double *Az)
 {
@@ -450,33 +494,37 @@ static int set_matrix_impl(mi355_factor *F, const int64_t *Ap, const int64_t *Ai
     const int64_t n = F->sym.n;
     F->have_A = false;
     F->not_posdef = false;
+    F->A_unsym = false;
     if (n == 0) { F->have_A = true; return MI355_OK; }
-    if (!Ap || !Ai || !Ax) return fail(MI355_INVALID, "null matrix array");
-    // extent of Ai/Ax actually referenced
-    int64_t nzmax = 0;
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t p = Ap[k], pend = Anz ? p + Anz[k] : Ap[k + 1];
-        if (p < 0 || pend < p) return fail(MI355_INVALID, "matrix column pointers invalid");
-        nzmax = std::max(nzmax, pend);
-    }
-    if (!Anz) nzmax = std::max(nzmax, Ap[n]);
-    for (int64_t p = 0; p < nzmax; p++)
-        if (Ai[p] < 0 || Ai[p] >= n) return fail(MI355_INVALID, "matrix row index out of range");
-    HIP_TRY(F->Ap.upload(Ap, (size_t)n + 1, F->stream));
-    HIP_TRY(F->Ai.upload(Ai, (size_t)nzmax, F->stream));
-    if (F->E == 2 && Az) {
-        // zomplex A: interleave, as the zd_ worker does on the fly (worker :69-83)
-        std::vector<double> z((size_t)nzmax * 2);
-        for (int64_t p = 0; p < nzmax; p++) { z[2 * p] = Ax[p]; z[2 * p + 1] = Az[p]; }
-        HIP_TRY(F->Ax.upload(z.data(), z.size(), F->stream));
-    } else {
-        if (F->E == 1 && Az) return fail(MI355_INVALID, "complex type mismatch: zomplex A with a real L");
-        HIP_TRY(F->Ax.upload(Ax, (size_t)nzmax * F->E, F->stream));
-    }
-    F->A_unpacked = (Anz != nullptr);
-    if (Anz) HIP_TRY(F->Anz.upload(Anz, (size_t)n, F->stream));
+    rc = stage_csc(F, n, n, Ap, Ai, Anz, Ax, Az, F->Ap, F->Ai, F->Anz, F->Ax, F->A_unpacked);
+    if (rc) return rc;
     F->have_A = true;
     F->A_perm = false;
+    return MI355_OK;
+}
+
+int mi355_factor_set_matrix_unsym(mi355_factor *F, int64_t ncol, const int64_t *Ap, const int64_t *Ai,
+                                  const int64_t *Anz, const double *Ax, const double *Az,
+                                  const int64_t *Fp, const int64_t *Fi, const int64_t *Fnz,
+                                  const double *Fx, const double *Fz)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    const int64_t n = F->sym.n;
+    F->have_A = false;
+    F->not_posdef = false;
+    if (ncol < 0) return fail(MI355_INVALID, "invalid dimensions");
+    if ((Az == nullptr) != (Fz == nullptr)) return fail(MI355_INVALID, "A and F must have same xtype and dtype");
+    if (n == 0) { F->have_A = true; F->A_unsym = false; return MI355_OK; }
+    if (!Fp || !Fi || !Fx) return fail(MI355_INVALID, "F invalid");
+    rc = stage_csc(F, ncol, n, Ap, Ai, Anz, Ax, Az, F->Ap, F->Ai, F->Anz, F->Ax, F->A_unpacked);
+    if (rc) return rc;
+    rc = stage_csc(F, n, ncol, Fp, Fi, Fnz, Fx, Fz, F->Fp, F->Fi, F->Fnz, F->Fx, F->F_unpacked);
+    if (rc) return rc;
+    F->A_unsym = true;
+    F->A_perm = false;
+    F->have_A = true;
     return MI355_OK;
 }
 

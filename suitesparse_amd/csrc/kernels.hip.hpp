@@ -3,6 +3,7 @@
 //
 // Kernel            replaces (reference)                                     bound
 // k_assemble        A-scatter + beta, worker :438-520                        HBM
+// k_assemble_aat    A*F accumulation for stype == 0, worker :471-506          HBM
 // k_relmap          Map/RelativeMap, worker :392-399,:896-903 and            HBM (once per symbolic)
 //                   kernelCreateMap/kernelCreateRelativeMap (CHOLMOD/GPU/cholmod_gpu_kernels.cu:21-41)
 // k_gemm64          dsyrk+dgemm+assembly (worker :769-930; cublasDsyrk/Dgemm +  FP64 MFMA
@@ -108,6 +109,54 @@ __global__ __launch_bounds__(256) void k_assemble_perm(
             Lx[2 * at + 1] = swap ? -Ax[2 * p + 1] : Ax[2 * p + 1];
         } else {
             Lx[at] = Ax[p];
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_assemble_aat: Lx <- tril(A*F) for stype == 0 (worker :471-506), one thread per column k of L:
+// column k = sum over the entries F(j,k) of A(:,j)*F(j,k), rows i >= k, accumulated in the reference's order
+// (pf ascending, then p ascending) by the one thread that owns the column -- no atomics, the same sum as the
+// reference's.  A is n x ncol, F = A' or A(:,f)' is ncol x n; entries outside the pattern of L are dropped
+// (:495-497).  Complex: L_MULTADD is a plain complex product (F already holds the conjugates).  k_add_beta follows.
+//------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_assemble_aat(
+    int64_t ncols, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+    const int64_t *__restrict__ Anz, const double *__restrict__ Ax,
+    const int64_t *__restrict__ Fp, const int64_t *__restrict__ Fi,
+    const int64_t *__restrict__ Fnz, const double *__restrict__ Fx,
+    const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
+    const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx,
+    const int32_t *__restrict__ Ls, double *__restrict__ Lx, const int8_t *__restrict__ smask)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int s = supermap[k];
+    if (smask && !smask[s]) return;
+    const int64_t k1 = Super[s], psi = Lpi[s];
+    const int nsrow = (int)(Lpi[s + 1] - psi);
+    const int64_t colbase = Lpx[s] + (k - k1) * (int64_t)nsrow;
+    int64_t pf = Fp[k];
+    const int64_t pfend = Fnz ? pf + Fnz[k] : Fp[k + 1];
+    for (; pf < pfend; pf++) {
+        const int64_t j = Fi[pf];
+        const double fr = Fx[E * pf], fi = (E == 2) ? Fx[E * pf + E - 1] : 0.0;
+        int64_t p = Ap[j];
+        const int64_t pend = Anz ? p + Anz[j] : Ap[j + 1];
+        for (; p < pend; p++) {
+            const int64_t i = Ai[p];
+            if (i < k) continue;
+            const int imap = find_row(Ls + psi, nsrow, (int)i);
+            if (imap < 0) continue;
+            const int64_t at = colbase + imap;
+            if (E == 2) {
+                const double ar = Ax[2 * p], ai = Ax[2 * p + 1];
+                Lx[2 * at] += ar * fr - ai * fi;
+                Lx[2 * at + 1] += ai * fr + ar * fi;
+            } else {
+                Lx[at] += Ax[p] * fr;
+            }
         }
     }
 }

@@ -38,7 +38,7 @@ EXPORTS = [
     "mi355_factor_set_matrix_perm", "mi355_factor_rcond", "mi355_factor_to_simplicial",
     "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
-    "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
+    "mi355_factor_set_matrix_unsym", "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
 ]
 
 _LIB = None
@@ -65,6 +65,8 @@ def lib():
         L.mi355_factor_free.argtypes = [C.c_void_p]
         L.mi355_factor_set_matrix.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p]
         L.mi355_factor_set_matrix_zomplex.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, _f64p]
+        L.mi355_factor_set_matrix_unsym.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, C.c_void_p, _f64p,
+                                                    C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, C.c_void_p]
         L.mi355_factor_numeric.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int)]
         L.mi355_factor_get_Lx.argtypes = [C.c_void_p, _f64p]
@@ -250,6 +252,30 @@ class SupernodalFactor:
         else:
             _check(lib().mi355_factor_set_matrix(self._h, Sp, Si, nz, Sx))
 
+    def set_matrix_unsym(self, ncol, Ap, Ai, Ax, Fp, Fi, Fx, Anz=None, Fnz=None, Az=None, Fz=None):
+        """stype == 0: the pair (A, F) of cholmod_super_numeric(A, F, beta, L); A is n x ncol, F = A' (conjugate
+        transpose) is ncol x n.  Ax/Fx complex arrays for a complex L, or real parts with Az/Fz (zomplex)."""
+        def vals(x, z):
+            if self.E == 2 and z is None:
+                return np.ascontiguousarray(x, dtype=np.complex128).view(np.float64)
+            if np.iscomplexobj(x):
+                raise Mi355Error(CHOLMOD_INVALID, "complex type mismatch: complex A with a real L")
+            return np.ascontiguousarray(x, dtype=np.float64)
+
+        def pad(a, k=1):
+            return a if a.size else np.zeros(k, dtype=a.dtype)
+        Ap, Ai, Fp, Fi = (np.ascontiguousarray(a, dtype=np.int64) for a in (Ap, Ai, Fp, Fi))
+        keep = []
+
+        def opt(a, dt):
+            if a is None:
+                return None
+            keep.append(np.ascontiguousarray(a, dtype=dt))
+            return keep[-1].ctypes.data_as(C.c_void_p)
+        _check(lib().mi355_factor_set_matrix_unsym(self._h, int(ncol), Ap, pad(Ai), opt(Anz, np.int64),
+                                                   pad(vals(Ax, Az), 2), opt(Az, np.float64), Fp, pad(Fi),
+                                                   opt(Fnz, np.int64), pad(vals(Fx, Fz), 2), opt(Fz, np.float64)))
+
     def numeric(self, beta=0.0, quick_return_if_not_posdef=False):
         """Factorize the staged matrix; everything stays in HBM.  Returns CHOLMOD status."""
         minor = C.c_int64(0)
@@ -259,10 +285,15 @@ class SupernodalFactor:
         self.minor, self.status = int(minor.value), int(status.value)
         return self.status
 
-    def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None, Sz=None):
-        """cholmod_super_numeric(S, NULL, beta, L): S = tril(P A P'), only beta[0] is used
+    def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None, Sz=None,
+                      F=None):
+        """cholmod_super_numeric(S, F, beta, L): S = tril(P A P') and F = None (stype < 0), or S = A(p,f) with
+        F = (Fp, Fi, Fx) = S' (stype == 0: A*F is factorized); only beta[0] is used
         (t_cholmod_super_numeric_worker.c:510-520).  Returns Common->status; sets self.minor."""
         b = beta[0] if isinstance(beta, (tuple, list, np.ndarray)) else beta
+        if F is not None:
+            self.set_matrix_unsym(len(Sp) - 1, Sp, Si, Sx, F[0], F[1], F[2], Anz=Snz)
+            return self.numeric(b, quick_return_if_not_posdef)
         self.set_matrix(Sp, Si, Sx, Snz, Sz)
         return self.numeric(b, quick_return_if_not_posdef)
 

@@ -65,6 +65,32 @@ def from_file(name, path, ordering="default", note=""):
     record(name, r, ordering, note or f"reference fixture {os.path.relpath(path, '/root/reference')}")
 
 
+def record_unsym(name, path, ordering="default", beta=0.0):
+    """stype == 0 fixtures (tests/golden/unsym/): the reference factorizes A*A' + beta*I from the pair
+    (S, F) = (A(p,:), A(p,:)') that cholmod_factorize hands to cholmod_super_numeric
+    (cholmod_factorize.c:201-210,240-250; worker :471-506)."""
+    r = RefCholmod()
+    m = r.read(path)
+    assert m["stype"] == 0
+    inf = r.analyze(ordering)
+    if not inf["is_super"]:
+        raise RuntimeError("not supernodal")
+    sym = r.symbolic()
+    (Sp, Si, Sx), (Fp, Fi, Fx) = r.permuted_unsym()
+    status = r.factorize(beta=beta)
+    inf = r.info()
+    out = dict(name=name, note=f"reference fixture {os.path.relpath(path, '/root/reference')}, A*A' + {beta}*I",
+               n=inf["n"], ncol=m["ncol"], stype=0, xtype=inf["xtype"], beta=beta, Ap=m["Ap"], Ai=m["Ai"], Ax=m["Ax"],
+               ordering=inf["ordering"], fl=inf["fl"], lnz=inf["lnz"], nsuper=inf["nsuper"], ssize=inf["ssize"],
+               xsize=inf["xsize"], maxcsize=inf["maxcsize"], maxesize=inf["maxesize"], Perm=sym["Perm"],
+               ColCount=sym["ColCount"], Super=sym["Super"], Lpi=sym["Lpi"], Lpx=sym["Lpx"], Ls=sym["Ls"],
+               Sp=Sp, Si=Si, Sx=Sx, Fp=Fp, Fi=Fi, Fx=Fx, Lx=r.Lx(), status=status, minor=inf["minor"])
+    os.makedirs(os.path.join(OUT, "unsym"), exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "unsym", name + ".npz"), **out)
+    print(f"unsym/{name:16s} {inf['n']:4d} x {m['ncol']:4d} xtype={inf['xtype']} ordering={inf['ordering_name']:8s} "
+          f"nsuper={inf['nsuper']:4d} xsize={inf['xsize']:6d} status={status} minor={inf['minor']}")
+
+
 def from_problem(name, p, ordering, note, negate_col=None, beta=0.0, user_perm=None):
     r = RefCholmod()
     Ax = p["Ax"].copy()
@@ -77,6 +103,22 @@ def from_problem(name, p, ordering, note, negate_col=None, beta=0.0, user_perm=N
 
 
 if __name__ == "__main__":
+    for nm, path, kw in (("lp_afiro", f"{REF}/Demo/Matrix/lp_afiro.tri", {}),
+                         ("pts5ldd03", f"{REF}/Demo/Matrix/pts5ldd03.mtx", {}),
+                         ("tcov_5by50", f"{REF}/Tcov/Matrix/5by50", {}),
+                         ("tcov_5by50_beta", f"{REF}/Tcov/Matrix/5by50", {"beta": 0.25}),
+                         ("tcov_c10", f"{REF}/Tcov/Matrix/c10", {}),
+                         ("tcov_c10_natural", f"{REF}/Tcov/Matrix/c10", {"ordering": "natural"}),
+                         ("tcov_galenet", f"{REF}/Tcov/Matrix/galenet", {}),
+                         ("tcov_ibm32", f"{REF}/Tcov/Matrix/ibm32", {})):
+        # (Tcov/Matrix/3_2 is left out: 3 x 2, A*A' is exactly singular and whether the last pivot comes out as
+        # +1e-17 or -1e-17 is rounding noise of the BLAS in use)
+        try:
+            record_unsym(nm, path, **kw)
+        except Exception as e:   # noqa: BLE001
+            print(f"unsym/{nm}: skipped ({e})")
+    if "--unsym-only" in sys.argv:
+        sys.exit(0)
     from_file("demo_bcsstk01", f"{REF}/Demo/Matrix/bcsstk01.tri")
     from_file("demo_bcsstk02", f"{REF}/Demo/Matrix/bcsstk02.tri")
     from_file("demo_c", f"{REF}/Demo/Matrix/c.tri")

@@ -26,7 +26,7 @@ struct Emu {
 void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t *Ap, const int64_t *Ai,
          const double *Ax, double beta, double *Lx, std::vector<double> &Dinv, std::vector<int> &info,
          const int8_t *asm_mask = nullptr, bool init = true, int64_t step0 = 0, int64_t step1 = -1,
-         bool keep_dinv = false)
+         bool keep_dinv = false, const int64_t *Fp = nullptr, const int64_t *Fi = nullptr, const double *Fx = nullptr)
 {
     if (init) std::fill(Lx, Lx + S.xsize, 0.0);
     info.assign(S.nsuper + 2, 0);
@@ -39,7 +39,15 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
         if (asm_mask && !asm_mask[s]) continue;
         int64_t k1 = S.Super[s], psi = S.Lpi[s], psx = S.Lpx[s], nsrow = S.Lpi[s + 1] - psi;
         int64_t base = psx + (k - k1) * nsrow;
-        for (int64_t p = Ap[k]; p < Ap[k + 1]; p++) {
+        // stype == 0 (mi355_factor_set_matrix_unsym): column k of A*F
+        for (int64_t pf = Fp ? Fp[k] : 0; Fp && pf < Fp[k + 1]; pf++) {
+            const int64_t j = Fi[pf];
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                int64_t i = Ai[p];
+                if (i >= k) { int im = find_row(S.Ls + psi, nsrow, i); if (im >= 0) Lx[base + im] += Ax[p] * Fx[pf]; }
+            }
+        }
+        for (int64_t p = Ap[k]; !Fp && p < Ap[k + 1]; p++) {
             int64_t i = Ai[p];
             if (i >= k) { int im = find_row(S.Ls + psi, nsrow, i); if (im >= 0) Lx[base + im] = Ax[p]; }
         }
@@ -150,17 +158,18 @@ int emu_check_tile_tables(int64_t n, int64_t nsuper, const int64_t *Super, const
 }
 
 // returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them
-int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
-                      const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
-                      const double *Ax, double beta, int quick, double *Lx, double *Dinv_out,
-                      int64_t *minor, int *status, int64_t *stats)
+int emu_super_numeric_f(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                        const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                        const double *Ax, const int64_t *Fp, const int64_t *Fi, const double *Fx,
+                        double beta, int quick, double *Lx, double *Dinv_out,
+                        int64_t *minor, int *status, int64_t *stats)
 {
     Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
     S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
     if (!validate_symbolic(S).empty()) return -4;
     Schedule sc; build_schedule(S, nsuper, 0, sc);
     std::vector<double> Dinv; std::vector<int> info;
-    run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info);
+    run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info, nullptr, true, 0, -1, false, Fp, Fi, Fx);
     if (info[nsuper + 1] != 0) return -10;
     if (stats) { stats[0] = sc.nlevels; stats[1] = (int64_t)sc.steps.size(); stats[2] = (int64_t)sc.pairs.size();
                  stats[3] = sc.relmap_size; stats[4] = sc.dinv_size; stats[5] = (int64_t)sc.gemm.size(); }
@@ -173,7 +182,7 @@ int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int
         int64_t nscol2 = (inf == 1 || quick) ? 0 : inf - 1;
         Schedule tr; build_schedule(S, sf, nscol2, tr);
         std::vector<int> info2;
-        run(S, tr, nscol2 > 0 ? Super[sf + 1] : Super[sf], Ap, Ai, Ax, beta, Lx, Dinv, info2);
+        run(S, tr, nscol2 > 0 ? Super[sf + 1] : Super[sf], Ap, Ai, Ax, beta, Lx, Dinv, info2, nullptr, true, 0, -1, false, Fp, Fi, Fx);
         if (info2[nsuper + 1] != 0) return -11;
         int64_t nsrow = Lpi[sf + 1] - Lpi[sf];
         int64_t tail = Lpx[sf] + nsrow * nscol2;
@@ -182,6 +191,15 @@ int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int
         std::copy(Dinv.begin(), Dinv.begin() + sc.dinv_size, Dinv_out);
     }
     return 0;
+}
+
+int emu_super_numeric(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                      const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                      const double *Ax, double beta, int quick, double *Lx, double *Dinv_out,
+                      int64_t *minor, int *status, int64_t *stats)
+{
+    return emu_super_numeric_f(n, nsuper, Super, Lpi, Lpx, Ls, ssize, xsize, Ap, Ai, Ax, nullptr, nullptr, nullptr,
+                               beta, quick, Lx, Dinv_out, minor, status, stats);
 }
 
 // one multi-GPU phase (mi355_factor_numeric_phase): masked schedule, optional init/assembly
