@@ -33,6 +33,21 @@ static void quiet_handler (int status, const char *file, int line, const char *m
     (void) status ; (void) file ; (void) line ; (void) msg ;
 }
 
+// column subset f for the unsymmetric case (cholmod_analyze_p / cholmod_factorize_p's fset): A(:,f)*A(:,f)' is
+// analyzed and factorized.  NULL / 0 = all columns.  Kept until the next call; used by ref_analyze and ref_permute.
+static int64_t *g_fset = NULL ;
+static size_t g_fsize = 0 ;
+void ref_set_fset (const int64_t *fset, int64_t fsize)
+{
+    free (g_fset) ; g_fset = NULL ; g_fsize = 0 ;
+    if (fset && fsize > 0)
+    {
+        g_fset = malloc (fsize * sizeof (int64_t)) ;
+        memcpy (g_fset, fset, fsize * sizeof (int64_t)) ;
+        g_fsize = (size_t) fsize ;
+    }
+}
+
 void *ref_new (void)
 {
     ref_ctx *h = calloc (1, sizeof (ref_ctx)) ;
@@ -170,7 +185,8 @@ int ref_analyze (void *hv, int ordering, const int64_t *perm, int supernodal)
         h->cm.nmethods = 0 ;
     }
     double t = SuiteSparse_time ( ) ;
-    h->L = cholmod_l_analyze_p (h->A, (int64_t *) perm, NULL, 0, &h->cm) ;
+    const int un = (h->A->stype == 0) ;
+    h->L = cholmod_l_analyze_p (h->A, (int64_t *) perm, un ? g_fset : NULL, un ? g_fsize : 0, &h->cm) ;
     h->t_analyze = SuiteSparse_time ( ) - t ;
     h->last_status = h->cm.status ;
     return (h->L == NULL) ? -1 : h->cm.status ;
@@ -226,12 +242,12 @@ int64_t ref_permute (void *hv)
         // F = A(p,:)' ; S = F'  (cholmod_factorize.c:201-210 natural, :240-250 permuted; no fset)
         if (L->ordering == CHOLMOD_NATURAL)
         {
-            h->F = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, &h->cm) ;
+            h->F = cholmod_l_ptranspose (A, 2, NULL, g_fset, g_fsize, &h->cm) ;
             h->S = A ;
         }
         else
         {
-            h->F = cholmod_l_ptranspose (A, 2, L->Perm, NULL, 0, &h->cm) ;
+            h->F = cholmod_l_ptranspose (A, 2, L->Perm, g_fset, g_fsize, &h->cm) ;
             h->S = h->F ? cholmod_l_ptranspose (h->F, 2, NULL, NULL, 0, &h->cm) : NULL ;
         }
         if (!h->S || !h->F) return -2 ;

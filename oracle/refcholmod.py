@@ -37,6 +37,7 @@ def lib():
         L.ref_load_matrix.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, f64p, C.c_int, C.c_int]
         L.ref_read_matrix.argtypes = [C.c_void_p, C.c_char_p]
         L.ref_load_matrix_rect.argtypes = [C.c_void_p, C.c_int64, C.c_int64, i64p, i64p, f64p, C.c_int]
+        L.ref_set_fset.argtypes = [C.c_void_p, C.c_int64]
         L.ref_F_info.argtypes = [C.c_void_p, i64p]
         L.ref_get_F.argtypes = [C.c_void_p, i64p, i64p, f64p]
         L.ref_matrix_info.argtypes = [C.c_void_p, i64p]
@@ -112,6 +113,14 @@ class RefCholmod:
             raise RuntimeError("ref_load_matrix_rect failed")
         self.n = nrow
         self.xtype = 2 if cplx else 1
+
+    def set_fset(self, fset=None):
+        """column subset of an unsymmetric matrix: A(:,f)*A(:,f)' is analyzed and factorized (None: all columns)"""
+        if fset is None:
+            self.L.ref_set_fset(None, 0)
+        else:
+            f = np.ascontiguousarray(fset, dtype=np.int64)
+            self.L.ref_set_fset(f.ctypes.data_as(C.c_void_p), f.size)
 
     def read(self, path):
         rc = self.L.ref_read_matrix(self.h, path.encode())
