@@ -11,9 +11,10 @@ factorization (zero Lx, assemble S, every level's POTRF/TRSM/trailing/update lau
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): disjoint etree subtrees are
 mapped to ranks, their contributions to the shared top supernodes are summed with one RCCL
-all-reduce, the top is factorized on every rank ("scaling": "strong" -- total work fixed).
+all-reduce, the top is factorized owner-computes over 1024-column blocks with one broadcast
+per finished block (MI355_TOP=replicated: on every rank) -- "scaling": "strong", total work fixed.
 
-Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (k_gemm64, FP64 MFMA);
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (k_gemm128, FP64 MFMA);
 `cpu_baseline` is the unchanged reference CPU worker (oracle/_ref) timed on the host cores
 on a bounded sample of the same workload.
 """
