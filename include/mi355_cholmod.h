@@ -274,7 +274,9 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * key 9: fewest right-hand sides that run the solves on the MFMA kernels (default 5; a complex factor: min(value, 3)); key 10: 0 = no solve groups (one
  * diagonal + one update launch per 64-column block instead of two per 256 columns); key 11 / 13: tiles per run of the
  * backward solve updates (scalar / MFMA kernels) = step tiles / value; key 12: 1 = look-ahead (far part of the outermost trailing updates on
- * a second stream, measured +1.6 % at 150^3, off by default); keys 3 and 6: retired. */
+ * a second stream, measured +1.6 % at 150^3, off by default); key 14: update tasks of at most one 64 x 64 tile with
+ * M*N*K <= value run one wave per task (k_gemm_tiny) instead of one workgroup per task (0 = off, the default: not
+ * measured on the device yet); keys 3 and 6: retired. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

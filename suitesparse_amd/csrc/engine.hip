@@ -304,6 +304,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             else if (cplx)
                 hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
+            else if (st.flags & STEP_TINY)
+                hipLaunchKernelGGL(k_gemm_tiny, dim3((unsigned)((st.ntiles + TINY_WAVES - 1) / TINY_WAVES)), dim3(64 * TINY_WAVES), 0, q,
+                                   D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, st.ntiles, F->Lx.p, D.relmap.p);
             else if (st.trsm && !st.big)
                 hipLaunchKernelGGL(k_trsm64, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p);
@@ -1499,6 +1502,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 11) tuning().solve_bwd_div = std::max(1, value);
     else if (key == 12) tuning().lookahead = value;
     else if (key == 13) tuning().solve_bwd_div_mma = std::max(1, value);
+    else if (key == 14) tuning().tiny_max = std::max(0, value);
     else if (key == 14) tuning().solve_fwd_div_mma = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;

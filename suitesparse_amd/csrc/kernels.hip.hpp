@@ -199,6 +199,42 @@ __global__ __launch_bounds__(256) void k_relmap(
 
 
 //------------------------------------------------------------------------------
+// k_gemm_tiny: the update tasks of a STEP_TINY launch (schedule.hpp), one WAVE per task, TINY_WAVES tasks per
+// workgroup: lane l computes entries l, l + 64, ... of the M x N result (column-major, M, N <= 64) as plain dot
+// products over K straight from global memory and applies them like k_gemm64's epilogue (entries on or below the
+// diagonal only; atomic scatter-subtract through the relative map, or direct subtract).  No LDS, no barrier, no
+// MFMA: for a task of a few dozen entries the 64 x 64 MFMA tile of k_gemm64 is all padding, and what bounds a
+// launch of several hundred thousand of them is how many tasks a CU holds in flight.
+//------------------------------------------------------------------------------
+constexpr int TINY_WAVES = 4;
+
+__global__ __launch_bounds__(64 * TINY_WAVES) void k_gemm_tiny(
+    const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, int64_t ntiles,
+    double *__restrict__ Lx, const int32_t *__restrict__ relmap)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * TINY_WAVES + wave;
+    if (e >= ntiles) return;                                // no barrier below: a wave may leave early
+    const GemmTask t = tasks[tile_tab[e].task];
+    const int M = t.M, N = t.N, K = t.K;
+    const double *__restrict__ A = Lx + t.a_off;
+    const double *__restrict__ B = Lx + t.b_off;
+    double *__restrict__ C = Lx + t.c_off;
+    const int64_t lda = t.lda, ldb = t.ldb, ldc = t.ldc;
+    const bool scatter = t.mode == GEMM_SCATTER_SUB;
+    const int32_t *__restrict__ rm = relmap + (scatter ? t.rm_off : 0);
+    for (int idx = lane; idx < M * N; idx += 64) {
+        const int n = idx / M, m = idx - n * M;
+        if (m < n) continue;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < K; k++) acc += A[m + (int64_t)k * lda] * B[n + (int64_t)k * ldb];
+        if (scatter) atomic_add_f64(C + rm[m] + (int64_t)rm[n] * ldc, -acc);
+        else C[m + (int64_t)n * ldc] -= acc;
+    }
+}
+
+//------------------------------------------------------------------------------
 // k_gemm64: batched C = A * B^T on v_mfma_f64_16x16x4_f64, 64x64 tile per workgroup
 // (4 waves as 2x2, each wave 32x32 = 2x2 MFMA blocks), K staged through LDS in steps
 // of 16, epilogue by mode (atomic scatter-subtract / direct subtract / overwrite).

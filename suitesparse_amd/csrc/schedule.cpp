@@ -153,16 +153,23 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, const Sy
 {
     if (tasks.empty()) return;
     const Tuning &tu = tuning();
-    for (int big = 1; big >= 0; big--) {
+    auto is_tiny = [&](const GemmTask &t) {
+        return tu.tiny_max > 0 && !S.cplx && !trsm && t.mode != GEMM_OVERWRITE && t.M <= TILE && t.N <= TILE &&
+               (int64_t)t.M * t.N * t.K <= tu.tiny_max;
+    };
+    // launch classes: 1 big-tile tasks, 0 small-tile tasks, 2 tiny tasks (small-tile geometry, STEP_TINY)
+    for (int cls : {1, 0, 2}) {
+        const int big = cls == 1 ? 1 : 0;
         Step st;
-        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm; st.flags = flags; st.pad = 0;
+        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm; st.flags = flags | (cls == 2 ? STEP_TINY : 0); st.pad = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
         st.tmap_off = (int64_t)out.gemm_tile_tab.size();
         std::vector<Schedule::TileEntry> seq;
         for (auto &t : tasks) {
             // a complex factor's big tile is 64 x 128 entries: the row threshold counts real rows
             const int is_big = (!S.no_big && (S.cplx ? 2 : 1) * t.M >= tu.big_min_m && t.N >= tu.big_min_n) ? 1 : 0;
-            if (is_big != big) continue;
+            const int c = is_big ? 1 : (is_tiny(t) ? 2 : 0);
+            if (c != cls) continue;
             const int tbig = big ? (S.cplx ? 2 : 1) : 0;
             int64_t nt = gemm_tiles(t.M, t.N, t.mode, tile_rows(tbig), tile_cols(tbig));
             if (nt == 0) continue;
@@ -633,6 +640,14 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
             }
         } else {
             if (st.first + st.count > (int64_t)sc.gemm.size()) return bad("gemm step range", (int64_t)i);
+            if (st.flags & STEP_TINY) {
+                // k_gemm_tiny takes one whole task per wave: one tile per task, update modes only, real factor
+                if (st.ntiles != st.count || st.big || st.trsm || S.cplx) return bad("tiny step shape", (int64_t)i);
+                for (int64_t k = 0; k < st.count; k++) {
+                    const GemmTask &t = sc.gemm[(size_t)(st.first + k)];
+                    if (t.big || t.mode == GEMM_OVERWRITE || t.M > TILE || t.N > TILE) return bad("task of tiny step", (int64_t)i);
+                }
+            }
             if (st.tmap_off < 0 || st.tmap_off + st.ntiles > (int64_t)sc.gemm_tile_tab.size()) return bad("gemm step tiles", (int64_t)i);
             for (int64_t b = 0; b < st.ntiles; b++) {      // every workgroup's (task, tile) inside its task
                 const Schedule::TileEntry e = sc.gemm_tile_tab[(size_t)(st.tmap_off + b)];

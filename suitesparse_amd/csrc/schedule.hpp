@@ -121,6 +121,13 @@ struct Step {
 // for workgroup slots behind the update's queued tiles and run twice as long, stream priorities
 // notwithstanding -- and the overlapped launches blur the per-kernel durations the roofline is built from.
 constexpr int32_t STEP_SIDE = 1, STEP_JOIN = 2;
+// STEP_TINY: every task of the step is a real update (not a TRSM) of at most one 64 x 64 tile with
+// M*N*K <= Tuning::tiny_max; the engine runs such a step with k_gemm_tiny, one WAVE per task (no LDS, no barrier,
+// four tasks per workgroup) instead of one workgroup per task.  The low levels of the tree are made of hundreds of
+// thousands of such tasks (2D 2000^2, level 0: 661 299 updates of a few entries each), where a launch is bound by
+// workgroup slots and the latency chain inside one workgroup, not by flops.  Tasks and tile table entries are the
+// ordinary ones (tile (0, 0) of a 64 x 64-tile task).  Off by default (tiny_max = 0) until measured on the device.
+constexpr int32_t STEP_TINY = 4;
 
 struct Symbolic {
     int64_t n = 0, nsuper = 0, ssize = 0, xsize = 0;
@@ -195,7 +202,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -131,6 +131,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 8) tuning().ob3 = value;
     else if (key == 11) tuning().solve_bwd_div = value;
     else if (key == 13) tuning().solve_bwd_div_mma = value;
+    else if (key == 14) tuning().tiny_max = value;
 }
 
 // tile tables of the schedule built for a complex factor (rectangular big tiles): 0 if every GEMM step's table
@@ -172,7 +173,9 @@ int emu_super_numeric_f(int64_t n, int64_t nsuper, const int64_t *Super, const i
     run(S, sc, n, Ap, Ai, Ax, beta, Lx, Dinv, info, nullptr, true, 0, -1, false, Fp, Fi, Fx);
     if (info[nsuper + 1] != 0) return -10;
     if (stats) { stats[0] = sc.nlevels; stats[1] = (int64_t)sc.steps.size(); stats[2] = (int64_t)sc.pairs.size();
-                 stats[3] = sc.relmap_size; stats[4] = sc.dinv_size; stats[5] = (int64_t)sc.gemm.size(); }
+                 stats[3] = sc.relmap_size; stats[4] = sc.dinv_size; stats[5] = (int64_t)sc.gemm.size();
+                 stats[6] = 0; stats[7] = 0;      // tasks in STEP_TINY launches, and those launches
+                 for (const Step &st : sc.steps) if (st.kind == STEP_GEMM && (st.flags & STEP_TINY)) { stats[6] += st.count; stats[7]++; } }
     *status = 0; *minor = n;
     int64_t sf = -1;
     for (int64_t s = 0; s < nsuper; s++) if (info[s]) { sf = s; break; }

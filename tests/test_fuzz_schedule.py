@@ -78,6 +78,7 @@ def test_random_structure_factor_and_solves(emu, kind, n, seed):  # noqa: F811
     emu.emu_set_tuning(0, int(rng.choice([64, 192]))); emu.emu_set_tuning(1, int(rng.choice([64, 96])))
     div = int(rng.choice([1, 4, 256]))
     emu.emu_set_tuning(11, div); emu.emu_set_tuning(13, div)
+    emu.emu_set_tuning(14, int(rng.choice([0, 256, 1 << 16])))          # tiny launch class off / narrow / wide
     try:
         so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
         st, minor, Lx, D = run_emu(emu, g)
@@ -108,7 +109,7 @@ def test_random_structure_factor_and_solves(emu, kind, n, seed):  # noqa: F811
             assert relerr(Lx2, Lo2) < 1e-11
             assert np.array_equal(Lx2 == 0, Lo2 == 0)
     finally:
-        for k, v in ((2, 256), (7, 1024), (0, 192), (1, 96), (11, 256), (13, 4096)):
+        for k, v in ((2, 256), (7, 1024), (0, 192), (1, 96), (11, 256), (13, 4096), (14, 0)):
             emu.emu_set_tuning(k, v)
 
 
@@ -121,7 +122,7 @@ def test_random_structure_partition_bounds(emu, kind, n, seed, world):  # noqa: 
     emu.emu_validate_partition.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, C.c_int,
                                            i8p, i8p, C.c_int, C.c_int, C.c_char_p, C.c_int]
     ob = int(rng.choice([64, 128]))
-    emu.emu_set_tuning(2, ob); emu.emu_set_tuning(7, 2 * ob)
+    emu.emu_set_tuning(2, ob); emu.emu_set_tuning(7, 2 * ob); emu.emu_set_tuning(14, int(rng.choice([0, 1 << 12])))
     try:
         owner = multigpu.partition(g, world, min_subtrees_per_rank=1)["owner"]
         for cplx in (0, 1):
@@ -132,4 +133,4 @@ def test_random_structure_partition_bounds(emu, kind, n, seed, world):  # noqa: 
                                                 (owner < 0).astype(np.int8), r, world, msg, 300)
                 assert rc == 0, (r, rc, msg.value.decode())
     finally:
-        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024)
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 0)

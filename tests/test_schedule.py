@@ -96,6 +96,34 @@ def test_dense_supernode_blocking(emu, n, ob, ob2):
     assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
 
 
+@pytest.mark.parametrize("tiny_max", [1, 64, 4096, 1 << 20])
+@pytest.mark.parametrize("name", ["lap3d_8_metis", "lap2d_16_metis", "elast27_4_metis", "demo_bcsstk01", "tcov_ex5lo",
+                                  "lap3d_8_npd200", "nd_lap2d_20"])
+def test_tiny_launch_class(emu, name, tiny_max):
+    """tuning key 14 (STEP_TINY, k_gemm_tiny): small update tasks move to launches of their own; the schedule still
+    reproduces the reference (status, minor, zero pattern), every task stays inside its arrays (the emulator runs
+    check_schedule_bounds, which also holds a tiny step to one tile per task and update modes only)"""
+    g = load_golden(name)
+    emu.emu_set_tuning(14, tiny_max)
+    try:
+        a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+        Lx, D = np.zeros(g["xsize"]), np.zeros(emu.emu_dinv_size(*a) + 1)
+        minor, st, stats = np.zeros(1, dtype=np.int64), C.c_int(0), np.zeros(8, dtype=np.int64)
+        rc = emu.emu_super_numeric(*a, g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64), g["beta"],
+                                   0, Lx, D, minor, C.byref(st), stats)
+    finally:
+        emu.emu_set_tuning(14, 0)
+    assert rc == 0
+    assert st.value == g["status"] and int(minor[0]) == g["minor"]
+    assert relerr(Lx, g["Lx"]) < 1e-12
+    if st.value == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+    if tiny_max >= 4096 and g["nsuper"] > 4:
+        assert stats[6] > 0 and stats[7] > 0            # tasks really went to tiny launches
+    if tiny_max == 1 << 20 and g["nsuper"] > 4:
+        assert stats[6] >= stats[2] // 2                # ... most of the update pairs of these small problems
+
+
 @pytest.mark.parametrize("name", REAL)
 def test_schedule_reproduces_reference(emu, name):
     g = load_golden(name)

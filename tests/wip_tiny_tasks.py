@@ -1,0 +1,57 @@
+"""NOT COLLECTED (no test_ prefix): GPU cases of the tiny launch class (tuning key 14, k_gemm_tiny), written while no
+GPU was available.  Run by name once a GPU is there:
+    python -m pytest tests/wip_tiny_tasks.py -m gpu -x -q
+and move into tests/test_gpu_parity.py when green; then measure `bench.py --problem lap2d --tune 14=<M*N*K>` against
+the default before turning the key on."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sym_of, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+    assert torch.cuda.is_available()
+    from suitesparse_amd import engine as e
+    return e
+
+
+@pytest.mark.parametrize("tiny_max", [64, 4096, 1 << 18])
+@pytest.mark.parametrize("name", ["lap3d_8_metis", "lap2d_16_metis", "elast27_4_metis", "demo_bcsstk01", "tcov_ex5lo",
+                                  "lap3d_8_npd200", "nd_lap2d_20", "lap3d_8_beta"])
+def test_tiny_launch_class_golden(engine, name, tiny_max):
+    g = load_golden(name)
+    engine.set_tuning(14, tiny_max)
+    try:
+        L = engine.SupernodalFactor(sym_of(g), xtype=g["xtype"])
+        st = L.super_numeric(g["Sp"], g["Si"], g["Sx"], beta=(g["beta"], 0.0))
+        Lx = L.Lx()
+        L.close()
+    finally:
+        engine.set_tuning(14, 0)
+    assert (st, L.minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-10
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+
+
+@pytest.mark.parametrize("kind,size", [("lap2d", 300), ("lap3d", 30)])
+def test_tiny_launch_class_same_factor_as_default(engine, kind, size):
+    from suitesparse_amd import problems, symbolic
+    p = {"lap2d": problems.laplacian_2d, "lap3d": problems.laplacian_3d}[kind](size)
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], symbolic.nd_grid_order(p["shape"], p["dof"]))
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    out = []
+    for tiny_max in (0, 2048):
+        engine.set_tuning(14, tiny_max)
+        try:
+            L = engine.SupernodalFactor(sym)
+            assert L.super_numeric(Sp, Si, Sx) == 0
+            out.append(L.Lx())
+            L.close()
+        finally:
+            engine.set_tuning(14, 0)
+    assert relerr(out[1], out[0]) < 1e-12
