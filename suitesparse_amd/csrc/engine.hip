@@ -71,6 +71,7 @@ struct DeviceSchedule {
     Schedule sched;
     DevBuf<GemmTask> gemm;
     DevBuf<PotrfTask> potrf;
+    DevBuf<int32_t> potrf_order;        // Schedule::potrf_order (empty unless the tiny classes are on)
     DevBuf<int32_t> relmap, solve_tmap;
     DevBuf<Schedule::TileEntry> gemm_tmap;
     // grouped solve sweep (built on first use)
@@ -151,6 +152,7 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
     }
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
+    if (!S.potrf_order.empty()) HIP_TRY(D.potrf_order.upload(S.potrf_order.data(), S.potrf_order.size(), F->stream));
     HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_tab.data(), S.gemm_tile_tab.size(), F->stream));
     HIP_TRY(D.solve_tmap.upload(S.solve_tile_task.data(), S.solve_tile_task.size(), F->stream));
     HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
@@ -287,8 +289,22 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
         if (st.kind == STEP_POTRF) {
             if (st.count > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many POTRF tasks in one step");
             tm.begin(1);
-            hipLaunchKernelGGL(cplx ? k_potrf64c : k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
-                               D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p);
+            if (cplx)
+                hipLaunchKernelGGL(k_potrf64c, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                                   D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p);
+            else if (!D.sched.potrf_order.empty()) {
+                // blocks of at most 16 columns first (one wave each), the others one workgroup each
+                const int32_t *ord = D.potrf_order.p + st.first;
+                if (st.nsmall > 0)
+                    hipLaunchKernelGGL(k_potrf16, dim3((unsigned)((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES)),
+                                       dim3(64 * POTRF16_WAVES), 0, F->stream, D.potrf.p + st.first, ord, (int64_t)st.nsmall,
+                                       F->Lx.p, F->Dinv.p, F->info.p);
+                if (st.count > st.nsmall)
+                    hipLaunchKernelGGL(k_potrf64, dim3((unsigned)(st.count - st.nsmall)), dim3(256), 0, F->stream,
+                                       D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p, ord + st.nsmall);
+            } else
+                hipLaunchKernelGGL(k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                                   D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p, (const int32_t *)nullptr);
             tm.end(1);
             F->st_npotrf += 1;
         } else {

@@ -703,11 +703,11 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane)      // srcl
 
 __global__ __launch_bounds__(256) void k_potrf64(
     const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
-    double *__restrict__ Dinv, int *__restrict__ info)
+    double *__restrict__ Dinv, int *__restrict__ info, const int32_t *__restrict__ order = nullptr)
 {
     __shared__ double Ls[NB][NB + 1];       // the block, factorized in place (row i, column j)
     __shared__ double Vs[NB][NB + 1];       // its inverse
-    const PotrfTask t = tasks[blockIdx.x];
+    const PotrfTask t = tasks[order ? order[blockIdx.x] : (int)blockIdx.x];
     const int tid = threadIdx.x;
     const int nb = t.nb;
     const int64_t lda = t.lda;
@@ -826,6 +826,70 @@ __global__ __launch_bounds__(256) void k_potrf64(
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx % nb, j = idx / nb;
             D[idx] = (i >= j) ? Vs[i][j] : 0.0;               // column-major, ld = nb
+        }
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_potrf16: the same for blocks of at most 16 columns (Schedule::potrf_order, Step::nsmall), one WAVE per block and
+// POTRF16_WAVES blocks per workgroup: the register factorization of k_potrf64's 16 x 16 diagonal step IS the whole
+// job here -- lane r loads row r of the block straight from global memory (coalesced along r for each column),
+// the factor goes back the same way, and lane c ends up with column c of the inverse, which is how Dinv stores it.
+// No LDS, no barrier.
+//------------------------------------------------------------------------------
+constexpr int POTRF16_WAVES = 4;
+
+__global__ __launch_bounds__(64 * POTRF16_WAVES) void k_potrf16(
+    const PotrfTask *__restrict__ tasks, const int32_t *__restrict__ order, int64_t ntasks,
+    double *__restrict__ Lx, double *__restrict__ Dinv, int *__restrict__ info)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15;
+    const int64_t e = (int64_t)blockIdx.x * POTRF16_WAVES + wave;
+    if (e >= ntasks) return;                                  // no barrier below
+    const PotrfTask t = tasks[order[e]];
+    const int nb = t.nb;                                      // <= 16 (checked on the host)
+    const int64_t lda = t.lda;
+    double *__restrict__ A = Lx + t.a_off;
+
+    // lane r (mod 16) holds row r; identity beyond nb; entries right of the diagonal are never consumed
+    double a[16], rs[16], w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        double v = (l15 == k) ? 1.0 : 0.0;
+        if (l15 < nb && k < nb) v = (l15 >= k) ? A[l15 + (int64_t)k * lda] : 0.0;
+        a[k] = v;
+    }
+    int fail_col = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double d = lane_bcast(a[j], j);
+        fail_col = (!(d > 0.0) && fail_col == 0) ? j + 1 : fail_col;
+        const double r = rsqrt(d);
+        rs[j] = r;
+        a[j] = (l15 == j) ? d * r : a[j] * r;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) a[k] -= a[j] * lane_bcast(a[j], k);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // W = inv(L): lane c holds column c, w[i] = (delta_ic - sum_{k<i} L[i][k] w[k]) / L[i][i]
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        double acc = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) acc -= lane_bcast(a[k], i) * w[k];
+        w[i] = acc * rs[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0 && fail_col != 0 && info[t.s] == 0) info[t.s] = t.col0 + fail_col;
+    if (lane < nb) {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k <= lane) A[lane + (int64_t)k * lda] = a[k];
+        if (t.dinv_off >= 0) {
+            double *__restrict__ D = Dinv + t.dinv_off + (int64_t)lane * nb;      // column `lane`, ld = nb
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (i < nb) D[i] = (i >= lane) ? w[i] : 0.0;
         }
     }
 }

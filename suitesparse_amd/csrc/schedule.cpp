@@ -161,7 +161,7 @@ void flush_gemm(Schedule &out, std::vector<GemmTask> &tasks, int level, const Sy
     for (int cls : {1, 0, 2}) {
         const int big = cls == 1 ? 1 : 0;
         Step st;
-        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm; st.flags = flags | (cls == 2 ? STEP_TINY : 0); st.pad = 0;
+        st.kind = STEP_GEMM; st.level = level; st.big = big; st.trsm = trsm; st.flags = flags | (cls == 2 ? STEP_TINY : 0); st.nsmall = 0;
         st.first = (int64_t)out.gemm.size(); st.count = 0; st.ntiles = 0; st.stiles = 0;
         st.tmap_off = (int64_t)out.gemm_tile_tab.size();
         std::vector<Schedule::TileEntry> seq;
@@ -479,9 +479,16 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 ti32++;
             }
             Step st;
-            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0; st.flags = 0; st.pad = 0;
+            st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0; st.flags = 0; st.nsmall = 0;
             st.first = (int64_t)out.potrf.size();
             st.count = (int64_t)pts.size();
+            if (tuning().tiny_max > 0 && !S.cplx) {
+                out.potrf_order.resize(out.potrf.size());           // steps of other schedules' making: none
+                for (int pass = 0; pass < 2; pass++)
+                    for (size_t i = 0; i < pts.size(); i++)
+                        if ((pts[i].nb <= 16) == (pass == 0)) out.potrf_order.push_back((int32_t)i);
+                for (auto &pt : pts) st.nsmall += (pt.nb <= 16) ? 1 : 0;
+            }
             st.ntiles = st.count;
             st.stiles = stiles;
             st.tmap_off = tmap_off;
@@ -633,6 +640,17 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         if (st.first < 0 || st.count < 0) return bad("step range", (int64_t)i);
         if (st.kind == STEP_POTRF) {
             if (st.first + st.count > (int64_t)sc.potrf.size()) return bad("potrf step range", (int64_t)i);
+            if (!sc.potrf_order.empty()) {
+                // the order list of the step: a permutation of its tasks, the nsmall blocks of <= 16 columns first
+                if (sc.potrf_order.size() != sc.potrf.size() || st.nsmall < 0 || st.nsmall > st.count) return bad("potrf order list", (int64_t)i);
+                std::vector<uint8_t> seen((size_t)st.count, 0);
+                for (int64_t k = 0; k < st.count; k++) {
+                    const int32_t o = sc.potrf_order[(size_t)(st.first + k)];
+                    if (o < 0 || o >= st.count || seen[(size_t)o]) return bad("potrf order entry of step", (int64_t)i);
+                    seen[(size_t)o] = 1;
+                    if ((sc.potrf[(size_t)(st.first + o)].nb <= 16) != (k < st.nsmall)) return bad("potrf order class of step", (int64_t)i);
+                }
+            } else if (st.nsmall != 0) return bad("potrf step without order list", (int64_t)i);
             if (st.tmap_off < 0 || st.tmap_off + st.stiles > (int64_t)sc.solve_tile_task.size()) return bad("potrf step solve tiles", (int64_t)i);
             for (int64_t b = 0; b < st.stiles; b++) {
                 const int32_t ti = sc.solve_tile_task[(size_t)(st.tmap_off + b)];

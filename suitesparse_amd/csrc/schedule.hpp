@@ -111,8 +111,9 @@ struct Step {
     int64_t ntiles;     // STEP_GEMM: total tiles (= grid size); STEP_POTRF: = count
     int64_t stiles;     // STEP_POTRF: row tiles (SOLVE_ROWS rows each) below the blocks, for the solves
     int64_t tmap_off;   // offset of this step's tile -> task table (gemm_tile_task / solve_tile_task)
-    int32_t flags;      // STEP_SIDE / STEP_JOIN
-    int32_t pad;
+    int32_t flags;      // STEP_SIDE / STEP_JOIN / STEP_TINY
+    int32_t nsmall;     // STEP_POTRF with Schedule::potrf_order: the first nsmall entries of the step's order list are
+                        // blocks of at most 16 columns (k_potrf16: one wave per block), the rest go to k_potrf64
 };
 // Look-ahead: the part of an outermost trailing update that lies beyond the NEXT outer block does not feed the
 // next block's panel chain, so it runs on a second stream (STEP_SIDE) next to that chain; whatever touches its
@@ -155,6 +156,12 @@ struct Schedule {
     std::vector<int32_t> level;         // height above the leaves
     int32_t nlevels = 0;
     std::vector<PotrfTask> potrf;
+    // With Tuning::tiny_max > 0 and a real factor: per POTRF step (same offsets as potrf[]), the step's task indices
+    // (relative to the step) with the blocks of at most 16 columns first -- 98 % of the diagonal blocks of a 2D
+    // problem, 85 % of a 3D one: k_potrf64 holds two workgroups per CU (its 64 x 64 LDS images), k_potrf16 keeps such
+    // a block in the registers of one wave and sixteen of them per CU.  The task order itself is left alone (the
+    // solve work lists are built over it).  Empty otherwise.
+    std::vector<int32_t> potrf_order;
     std::vector<GemmTask> gemm;
     std::vector<UpdatePair> pairs;
     std::vector<Step> steps;

@@ -158,6 +158,25 @@ int emu_check_tile_tables(int64_t n, int64_t nsuper, const int64_t *Super, const
     return bad;
 }
 
+// launch classes of the full schedule under the current tuning: out[0] tasks in STEP_TINY launches, out[1] those
+// launches, out[2] diagonal blocks of <= 16 columns listed first in potrf_order, out[3] all diagonal blocks,
+// out[4] 1 if check_schedule_bounds accepts the schedule
+int emu_schedule_classes(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                         const int64_t *Ls, int64_t ssize, int64_t xsize, int64_t *out)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    if (!validate_symbolic(S).empty()) return -4;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    out[0] = out[1] = out[2] = 0; out[3] = (int64_t)sc.potrf.size();
+    for (const Step &st : sc.steps) {
+        if (st.kind == STEP_GEMM && (st.flags & STEP_TINY)) { out[0] += st.count; out[1]++; }
+        if (st.kind == STEP_POTRF) out[2] += st.nsmall;
+    }
+    out[4] = check_schedule_bounds(S, sc).empty() ? 1 : 0;
+    return 0;
+}
+
 // returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them
 int emu_super_numeric_f(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
                         const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,

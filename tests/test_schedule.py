@@ -118,6 +118,17 @@ def test_tiny_launch_class(emu, name, tiny_max):
     assert relerr(Lx, g["Lx"]) < 1e-12
     if st.value == 1:
         assert np.array_equal(Lx == 0, g["Lx"] == 0)
+    cls = np.zeros(8, dtype=np.int64)
+    emu.emu_schedule_classes.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p]
+    emu.emu_set_tuning(14, tiny_max)
+    try:
+        assert emu.emu_schedule_classes(*a, cls) == 0
+    finally:
+        emu.emu_set_tuning(14, 0)
+    assert cls[4] == 1
+    nb = np.concatenate([np.minimum(64, w - np.arange(0, w, 64)) for w in np.diff(g["Super"])])
+    if st.value == 0:
+        assert cls[3] == nb.size and cls[2] == (nb <= 16).sum()      # every block of <= 16 columns is in the wave class
     if tiny_max >= 4096 and g["nsuper"] > 4:
         assert stats[6] > 0 and stats[7] > 0            # tasks really went to tiny launches
     if tiny_max == 1 << 20 and g["nsuper"] > 4:

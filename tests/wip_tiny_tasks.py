@@ -55,3 +55,45 @@ def test_tiny_launch_class_same_factor_as_default(engine, kind, size):
         finally:
             engine.set_tuning(14, 0)
     assert relerr(out[1], out[0]) < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 33, 80])
+def test_small_dense_supernode_through_the_wave_potrf(engine, n):
+    """blocks of <= 16 columns go to k_potrf16 (one wave per block): n <= 16 is such a block without rows below it,
+    n = 17, 33, 80 end in one after full 64-column (or wider) blocks"""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    sym = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n]), Lpi=np.array([0, n]),
+               Lpx=np.array([0, n * n]), Ls=np.arange(n))
+    Sp = np.arange(n + 1, dtype=np.int64) * n
+    Si = np.tile(np.arange(n, dtype=np.int64), n)
+    Sx = np.ascontiguousarray(A.T).reshape(-1)
+    engine.set_tuning(14, 4096)
+    try:
+        L = engine.SupernodalFactor(sym)
+        assert L.super_numeric(Sp, Si, Sx) == 0
+        Lg = L.Lx().reshape(n, n).T
+        b = rng.standard_normal(n)
+        x = L.super_ltsolve(L.super_lsolve(b))
+        L.close()
+    finally:
+        engine.set_tuning(14, 0)
+    assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
+    assert relerr(x, np.linalg.solve(A, b)) < 1e-9
+
+
+def test_wave_potrf_reports_the_first_bad_pivot(engine):
+    """info from k_potrf16: a negative pivot inside a block of <= 16 columns (status, minor, zero pattern)"""
+    from oracle import port
+    g = load_golden("lap2d_16_npd0")
+    engine.set_tuning(14, 4096)
+    try:
+        L = engine.SupernodalFactor(sym_of(g))
+        st = L.super_numeric(g["Sp"], g["Si"], g["Sx"])
+        Lx = L.Lx()
+        L.close()
+    finally:
+        engine.set_tuning(14, 0)
+    assert (st, L.minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-10 and np.array_equal(Lx == 0, g["Lx"] == 0)
