@@ -106,7 +106,7 @@ class PartitionedFactor:
     every tensor over the ranks (default: torch.distributed all_reduce = RCCL on GPUs)."""
 
     def __init__(self, factor, sym, rank, world, allreduce=None, min_subtrees_per_rank=2, distribute_top=None,
-                 bcast=None):
+                 bcast=None, reduce=None):
         self.f, self.rank, self.world = factor, rank, world
         self.n = int(sym["n"])
         self.Super = sym["Super"]
@@ -121,6 +121,13 @@ class PartitionedFactor:
         self.tensors = factor.top_tensors(self.part["top_ranges"])
         self.allreduce = allreduce or self._dist_allreduce
         self.bcast = bcast or self._dist_bcast
+        # owner-computes top: only the owner of a block needs the sum of the ranks' contributions to it, everybody
+        # else gets the finished block by broadcast -- so the top panels are REDUCED block by block to their owners
+        # (half the volume of the all-reduce per rank; MI355_TOP_REDUCE=allreduce keeps the all-reduce).  A caller
+        # that brings its own all-reduce and no reduce keeps the all-reduce.
+        self.reduce = reduce or (self._dist_reduce if allreduce is None else None)
+        if os.environ.get("MI355_TOP_REDUCE", "owner") == "allreduce":
+            self.reduce = None
         self.status, self.minor = 0, self.n
         if distribute_top is None:
             distribute_top = os.environ.get("MI355_TOP", "distributed") != "replicated"
@@ -128,6 +135,17 @@ class PartitionedFactor:
         if self.dist:
             self.plan, (dlo, dhi) = factor.set_top_distribution(rank, world)
             self.bviews = factor.top_tensors([(int(lo), int(lo + cnt)) for _, lo, cnt, _ in self.plan])
+            # the blocks of the plan tile the top panels exactly (each column of a top supernode in one block):
+            # what lets the per-block reduce stand in for the all-reduce of the ranges
+            blocks = sorted((int(lo), int(lo + cnt)) for _, lo, cnt, _ in self.plan)
+            merged = []
+            for lo, hi in blocks:
+                if merged and merged[-1][1] == lo:
+                    merged[-1] = (merged[-1][0], hi)
+                else:
+                    merged.append((lo, hi))
+            if merged != [(int(a), int(b)) for a, b in self.part["top_ranges"]]:
+                self.reduce = None        # never expected; the all-reduce is always right
             self.dinv_views = factor.dinv_tensors([(dlo, dhi)]) if dhi > dlo else []
 
     @staticmethod
@@ -141,6 +159,18 @@ class PartitionedFactor:
             # before the collective has finished on the communication stream
             import torch
             torch.cuda.synchronize()
+
+    @staticmethod
+    def _dist_reduce(tensors, roots):
+        """sum tensors[k] over the ranks into rank roots[k]; the other ranks' copies are overwritten by the block's
+        broadcast before anything reads them"""
+        import torch.distributed as dist
+        work = [dist.reduce(t, dst=int(r), op=dist.ReduceOp.SUM, async_op=True) for t, r in zip(tensors, roots)]
+        for w in work:
+            w.wait()
+        if tensors and tensors[0].is_cuda:
+            import torch
+            torch.cuda.synchronize()      # the engine's stream is non-blocking: nothing of it may start before the sums are in
 
     @staticmethod
     def _dist_bcast(tensor, root):
@@ -207,7 +237,10 @@ class PartitionedFactor:
         if self._agree(bad, info) >= 0:
             return self._replay(beta, quick_return_if_not_posdef)
         if self.world > 1 and self.tensors:
-            self.allreduce(self.tensors)
+            if self.dist and self.reduce is not None:
+                self.reduce(self.bviews, [int(r) for r in self.plan[:, 3]])
+            else:
+                self.allreduce(self.tensors)
         if self.dist:
             bad, info = self._top_distributed()
             if self._agree(bad, info) < 0 and self.dinv_views:

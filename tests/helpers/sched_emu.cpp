@@ -490,4 +490,34 @@ int emu_validate_partition(int64_t n, int64_t nsuper, const int64_t *Super, cons
     }
     return 0;
 }
+
+// planning figures of one rank of a partition (no numeric work): out[0] executed flops of the own subtrees (phase 0),
+// out[1] of this rank's share of the distributed top, out[2] of the whole top when replicated, out[3] POTRF steps
+// (= length of the dependent panel chain) of phase 0, out[4] of the distributed top schedule, out[5] broadcasts,
+// out[6] entries broadcast in total, out[7] entries this rank sends as root, out[8] GEMM launches of the
+// distributed top, out[9] launches (all kinds) of phase 0
+int emu_partition_plan(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                       const int64_t *Ls, int64_t ssize, int64_t xsize, const int8_t *local_mask,
+                       const int8_t *top_mask, int rank, int world, double *out)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule loc, top, dst;
+    build_schedule(S, nsuper, 0, loc, local_mask);
+    build_schedule(S, nsuper, 0, top, top_mask, loc.dinv_size);
+    DistTop dt; dt.rank = rank; dt.world = world;
+    build_schedule(S, nsuper, 0, dst, top_mask, loc.dinv_size, &dt);
+    auto count = [](const Schedule &sc, int kind) { int64_t c = 0; for (const Step &st : sc.steps) if (st.kind == kind) c++; return (double)c; };
+    out[0] = loc.flops_update + loc.flops_panel;
+    out[1] = dst.flops_update + dst.flops_panel;
+    out[2] = top.flops_update + top.flops_panel;
+    out[3] = count(loc, STEP_POTRF);
+    out[4] = count(dst, STEP_POTRF);
+    out[5] = (double)dst.bcasts.size();
+    out[6] = out[7] = 0;
+    for (const BcastPoint &b : dst.bcasts) { out[6] += (double)b.count; if (b.root == rank) out[7] += (double)b.count; }
+    out[8] = count(dst, STEP_GEMM);
+    out[9] = (double)loc.steps.size();
+    return 0;
+}
 }

@@ -274,6 +274,46 @@ def test_not_posdef_on_a_partition_replays_the_reference_protocol(where, quick):
         assert ((rn.f.Lx == 0) == (Lo == 0)).all()
 
 
+@pytest.mark.parametrize("kind,size,world,ob2", [("lap3d", 14, 4, 128), ("lap3d", 12, 3, 1024), ("lap2d", 40, 8, 64),
+                                                 ("elast", 5, 2, 64)])
+def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2):
+    """the blocks of the broadcast plan tile the top panels exactly, so reducing every block to its owner replaces the
+    all-reduce: simulated ranks, the reduction done by hand block by block (non-owners keep their partial sums, as
+    after a real reduce), then the distributed top; every rank must end with the oracle's factor"""
+    from oracle import port
+    g = problem(kind, size)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    emu = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    emu.emu_set_tuning(2, min(64, ob2)); emu.emu_set_tuning(7, ob2)
+    try:
+        facs = [EmuFactor(g) for _ in range(world)]
+        calls = []
+        runners = [multigpu.PartitionedFactor(f, g, r, world, distribute_top=True, min_subtrees_per_rank=1,
+                                              reduce=lambda ts, roots: calls.append(len(ts)))
+                   for r, f in enumerate(facs)]
+        assert all(rn.dist and rn.reduce is not None for rn in runners)
+        covered = sum(int(c) for c in runners[0].plan[:, 2])
+        assert covered == sum(hi - lo for lo, hi in runners[0].part["top_ranges"])
+        for rn in runners:
+            assert rn.f.numeric_phase(0) == (-1, 0)
+        for k, (step, lo, cnt, root) in enumerate(runners[0].plan):      # what dist.reduce(dst=root) leaves behind
+            tot = sum(rn.bviews[k].clone() for rn in runners)
+            runners[int(root)].bviews[k][...] = tot
+        res = run_distributed_lockstep(runners, facs)
+        assert all(r == (-1, 0) for r in res)
+        owner = runners[0].part["owner"]
+        for r, f in enumerate(facs):
+            for s in range(g["nsuper"]):
+                if owner[s] == r or owner[s] == -1:
+                    a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                    nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                    got, want = f.Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                    low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+                    assert relerr(got[low], want[low]) < 1e-11, (r, s)
+    finally:
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024)
+
+
 def run_distributed_lockstep(runners, facs):
     """the owner-computes top with simulated ranks: every rank runs segment k, then block k travels"""
     plans = [rn.plan for rn in runners]
@@ -427,6 +467,7 @@ f = tm.EmuFactor(g)
 f.E.emu_set_tuning(2, 64); f.E.emu_set_tuning(7, 64)     # 64-column outer blocks: the top spreads over both ranks
 run = multigpu.PartitionedFactor(f, g, rank, world, min_subtrees_per_rank=1)
 assert run.dist and len(set(int(r) for r in run.plan[:, 3])) == 2
+assert run.reduce is not None          # the top panels go to their owners block by block (dist.reduce), no all-reduce
 st = run.numeric()
 so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
 owner = run.part["owner"]
