@@ -491,13 +491,15 @@ run2 = multigpu.PartitionedFactor(f2, g2, rank, world)
 st2 = run2.numeric()
 so2, mo2, _ = port.super_numeric(g2, g2["Sp"], g2["Si"], g2["Sx"])
 print("RESULT", rank, st, worst, st2, run2.minor, so2, mo2, flush=True)
+with open(os.path.join({out!r}, f"result_{{rank}}.txt"), "w") as fh:      # stdout of two ranks can interleave
+    fh.write(f"RESULT {{rank}} {{st}} {{worst}} {{st2}} {{run2.minor}} {{so2}} {{mo2}}\n")
 dist.destroy_process_group()
 '''
 
 
 def test_two_process_gloo_run(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     import socket
     for attempt in range(2):                         # the rendezvous port can be taken between probe and use: once more
@@ -510,7 +512,7 @@ def test_two_process_gloo_run(tmp_path):
         if out.returncode == 0 or "RESULT" in out.stdout:
             break
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    lines = [open(tmp_path / f"result_{r}.txt").read().split() for r in range(2)]
     assert len(lines) == 2
     for l in lines:
         st, worst, st2, minor2, so2, mo2 = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7])
