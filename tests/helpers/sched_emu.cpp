@@ -10,6 +10,84 @@
 #include <algorithm>
 using namespace mi355;
 
+// ---- the product's host-runnable kernels (the marked region of kernels.hip.hpp, cut out by build() into
+// _host_kernels.inc), executed thread by thread: stand-ins for the handful of HIP names they use.  These kernels
+// have no barrier, no LDS and no wave intrinsic, so running their threads one after the other is exact.
+// The wave-runnable pieces (k_potrf16: v_readlane, nothing else) run with one host thread per lane; a readlane is two
+// barriers around a 64-entry exchange array, which is exact as long as the whole wave reaches it (it does: the only
+// early exit of k_potrf16 is wave-uniform).
+#include <pthread.h>
+#include <thread>
+namespace hostrun {
+struct Dim { unsigned x = 0, y = 0, z = 0; };
+thread_local Dim threadIdx, blockIdx, blockDim;
+inline double unsafeAtomicAdd(double *p, double v) { const double o = *p; *p += v; return o; }
+struct Wave { pthread_barrier_t bar; int slot[64]; };
+thread_local Wave *wave = nullptr;
+thread_local int lane_id = 0;
+inline int readlane(int v, int src)
+{
+    wave->slot[lane_id] = v;
+    pthread_barrier_wait(&wave->bar);
+    const int r = wave->slot[src];
+    pthread_barrier_wait(&wave->bar);
+    return r;
+}
+inline int double2loint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
+inline int double2hiint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline double hiloint2double(int hi, int lo) { const int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &b, 8); return d; }
+inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }
+}
+#define __global__
+#define __device__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __builtin_amdgcn_readlane hostrun::readlane
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __double2loint hostrun::double2loint
+#define __double2hiint hostrun::double2hiint
+#define __hiloint2double hostrun::hiloint2double
+namespace mi355 {
+using hostrun::threadIdx; using hostrun::blockIdx; using hostrun::blockDim; using hostrun::unsafeAtomicAdd; using hostrun::rsqrt;
+#include "_host_kernels.inc"
+}
+#undef __global__
+#undef __device__
+#undef __forceinline__
+#undef __launch_bounds__
+#undef __builtin_amdgcn_readlane
+#undef __builtin_amdgcn_sched_barrier
+#undef __double2loint
+#undef __double2hiint
+#undef __hiloint2double
+namespace hostrun {
+// one host thread per lane, wave after wave
+template <class F> void launch_waves(int64_t grid, unsigned block, F kernel_call)
+{
+    for (int64_t b = 0; b < grid; b++)
+        for (unsigned w = 0; w < block / 64; w++) {
+            Wave ctx;
+            pthread_barrier_init(&ctx.bar, nullptr, 64);
+            std::vector<std::thread> th;
+            for (int l = 0; l < 64; l++)
+                th.emplace_back([&, l] {
+                    blockDim.x = block; blockIdx.x = (unsigned)b; threadIdx.x = w * 64 + l;
+                    wave = &ctx; lane_id = l;
+                    kernel_call();
+                });
+            for (auto &t : th) t.join();
+            pthread_barrier_destroy(&ctx.bar);
+        }
+}
+template <class F> void launch(int64_t grid, unsigned block, F kernel_call)
+{
+    blockDim.x = block;
+    for (int64_t b = 0; b < grid; b++)
+        for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; kernel_call(); }
+}
+int use_device_source = 0;              // emu_set_tuning(100, v): 1 = the thread-by-thread kernels, 2 = also the wave kernels
+}
+
 namespace {
 int find_row(const int64_t *a, int64_t len, int64_t key)
 {
@@ -34,7 +112,23 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
     if (!check_schedule_bounds(S, sc).empty()) { info[S.nsuper + 1] = -1; return; }
     if (!keep_dinv) Dinv.assign(sc.dinv_size + 1, 0.0);
     if (step1 < 0) step1 = (int64_t)sc.steps.size();
-    for (int64_t k = 0; init && k < ncols_asm; k++) {
+    const bool dev = hostrun::use_device_source != 0;
+    std::vector<int32_t> ls32;
+    if (dev) { const int64_t nls = S.Lpi[S.nsuper]; ls32.resize((size_t)nls + 1); for (int64_t i = 0; i < nls; i++) ls32[i] = (int32_t)S.Ls[i]; }
+    if (dev && init && ncols_asm > 0) {
+        // the engine's assembly launches (run_schedule), same arguments
+        const int64_t grid = (ncols_asm + 255) / 256;
+        if (Fp) {
+            hostrun::launch(grid, 256, [&] { k_assemble_aat<1>(ncols_asm, Ap, Ai, nullptr, Ax, Fp, Fi, nullptr, Fx, sc.supermap.data(),
+                                                                 S.Super, S.Lpi, S.Lpx, ls32.data(), Lx, asm_mask); });
+            if (beta != 0.0)
+                hostrun::launch(grid, 256, [&] { k_add_beta<1>(ncols_asm, beta, sc.supermap.data(), S.Super, S.Lpi, S.Lpx, Lx, asm_mask); });
+        } else {
+            hostrun::launch(grid, 256, [&] { k_assemble(ncols_asm, Ap, Ai, nullptr, Ax, sc.supermap.data(), S.Super, S.Lpi, S.Lpx,
+                                                        ls32.data(), Lx, beta, asm_mask); });
+        }
+    }
+    for (int64_t k = 0; !dev && init && k < ncols_asm; k++) {
         int s = sc.supermap[k];
         if (asm_mask && !asm_mask[s]) continue;
         int64_t k1 = S.Super[s], psi = S.Lpi[s], psx = S.Lpx[s], nsrow = S.Lpi[s + 1] - psi;
@@ -55,6 +149,17 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
     }
     // relative maps
     std::vector<int32_t> relmap(sc.relmap_size + 1);
+    if (dev && sc.relmap_size > 0) {
+        // upload_schedule's k_relmap launch
+        std::vector<RelmapPair> rp(sc.pairs.size());
+        for (size_t i = 0; i < rp.size(); i++) {
+            rp[i].ls_src = sc.pairs[i].ls_src; rp[i].ls_dst = sc.pairs[i].ls_dst;
+            rp[i].rm_off = sc.pairs[i].rm_off; rp[i].nsrow = sc.pairs[i].nsrow; rp[i].pad = 0;
+        }
+        int err = 0;
+        hostrun::launch((sc.relmap_size + 255) / 256, 256, [&] { k_relmap(sc.relmap_size, (int64_t)rp.size(), rp.data(), ls32.data(), relmap.data(), &err); });
+        if (err) { info[S.nsuper + 1] = -1; return; }
+    } else
     for (const UpdatePair &u : sc.pairs)
         for (int i = 0; i < u.ndrow2; i++)
             relmap[u.rm_off + i] = find_row(S.Ls + u.ls_dst, u.nsrow, S.Ls[u.ls_src + i]);
@@ -62,7 +167,18 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
     for (int64_t si = step0; si < step1; si++) {
         const Step &st = sc.steps[(size_t)si];
         if (st.kind == STEP_POTRF) {
-            for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+            std::vector<int64_t> todo;
+            if (hostrun::use_device_source >= 2 && !sc.potrf_order.empty()) {
+                // the engine's launches: k_potrf16 (from its own source) over the first nsmall entries of the order
+                // list, the wider blocks by the loops below
+                const int32_t *ord = sc.potrf_order.data() + st.first;
+                if (st.nsmall > 0)
+                    hostrun::launch_waves((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
+                        k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
+                for (int64_t k = st.nsmall; k < st.count; k++) todo.push_back(st.first + ord[k]);
+            } else
+                for (int64_t ti = st.first; ti < st.first + st.count; ti++) todo.push_back(ti);
+            for (int64_t ti : todo) {
                 const PotrfTask &t = sc.potrf[ti];
                 double *A = Lx + t.a_off; int nb = t.nb; int64_t lda = t.lda;
                 bool failed = false;
@@ -85,6 +201,11 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                     for (int i = 0; i < nb; i++) D[i + c * nb] = (i >= c) ? x[i] : 0.0;
                 }
             }
+        } else if (dev && (st.flags & STEP_TINY)) {
+            // the engine's k_gemm_tiny launch of this step
+            hostrun::launch((st.ntiles + TINY_WAVES - 1) / TINY_WAVES, 64 * TINY_WAVES, [&] {
+                k_gemm_tiny(sc.gemm.data() + st.first, sc.gemm_tile_tab.data() + st.tmap_off, st.ntiles, Lx, relmap.data()); });
+            if (!check_tile_table(sc, st)) info[S.nsuper + 1] = -1;
         } else {
             int64_t tiles = 0;
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
@@ -132,6 +253,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 11) tuning().solve_bwd_div = value;
     else if (key == 13) tuning().solve_bwd_div_mma = value;
     else if (key == 14) tuning().tiny_max = value;
+    else if (key == 100) hostrun::use_device_source = value;    // run the product's host-runnable kernels
 }
 
 // tile tables of the schedule built for a complex factor (rectangular big tiles): 0 if every GEMM step's table
@@ -156,6 +278,40 @@ int emu_check_tile_tables(int64_t n, int64_t nsuper, const int64_t *Super, const
     }
     if (nbig_tiles) *nbig_tiles = nb;
     return bad;
+}
+
+// The product's assembly kernels alone, from their own source (E = 1 real, 2 complex interleaved):
+//   kind 0: k_assemble / k_assemble_c (S = tril(PAP'));  1: k_assemble_perm<E> + k_add_beta<E> (A + inverse permutation);
+//   2: k_assemble_aat<E> + k_add_beta<E> (stype == 0: A n x ncol in Ap/Ai/Ax, F in Fp/Fi/Fx).  Lx (E*xsize) is zeroed first.
+int emu_device_assemble(int kind, int E, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                        const int64_t *Lpx, const int64_t *Ls, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                        const int64_t *Anz, const double *Ax, const int64_t *Fp, const int64_t *Fi, const int64_t *Fnz,
+                        const double *Fx, const int64_t *iperm, double beta, double *Lx)
+{
+    std::vector<int32_t> supermap((size_t)n + 1), ls32((size_t)Lpi[nsuper] + 1);
+    for (int64_t s = 0; s < nsuper; s++) for (int64_t k = Super[s]; k < Super[s + 1]; k++) supermap[k] = (int32_t)s;
+    for (int64_t i = 0; i < Lpi[nsuper]; i++) ls32[i] = (int32_t)Ls[i];
+    std::fill(Lx, Lx + (size_t)xsize * E, 0.0);
+    const int64_t grid = (n + 255) / 256;
+    const int8_t *nomask = nullptr;
+    if (kind == 0 && E == 1)
+        hostrun::launch(grid, 256, [&] { k_assemble(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
+    else if (kind == 0)
+        hostrun::launch(grid, 256, [&] { k_assemble_c(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
+    else if (kind == 1 && E == 1)
+        hostrun::launch(grid, 256, [&] { k_assemble_perm<1>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+    else if (kind == 1)
+        hostrun::launch(grid, 256, [&] { k_assemble_perm<2>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+    else if (kind == 2 && E == 1)
+        hostrun::launch(grid, 256, [&] { k_assemble_aat<1>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+    else if (kind == 2)
+        hostrun::launch(grid, 256, [&] { k_assemble_aat<2>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+    else return -1;
+    if (kind != 0 && beta != 0.0) {
+        if (E == 1) hostrun::launch(grid, 256, [&] { k_add_beta<1>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
+        else hostrun::launch(grid, 256, [&] { k_add_beta<2>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
+    }
+    return 0;
 }
 
 // launch classes of the full schedule under the current tuning: out[0] tasks in STEP_TINY launches, out[1] those

@@ -1,0 +1,165 @@
+"""The product's own kernel source, executed on the CPU.  build() cuts the marked host-runnable region out of
+suitesparse_amd/csrc/kernels.hip.hpp (assembly kernels, k_relmap, k_gemm_tiny: no barrier, no LDS, no wave intrinsic)
+and the emulator runs those kernels thread by thread with the engine's launch geometry and arguments (emulator key 100)
+in place of its own plain loops.  Checked against the reference's golden outputs / the oracle -- a GPU-less check of the
+device code itself, not only of the host logic around it."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden, relerr, sym_of
+from test_schedule import emu, run_emu  # noqa: F401
+import test_unsym as tu
+
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+REAL = [n for n in golden_names() if load_golden(n)["xtype"] == 1]
+
+
+@pytest.mark.parametrize("tiny_max", [0, 4096, 1 << 20])
+@pytest.mark.parametrize("name", REAL)
+def test_factorization_through_the_device_source(emu, name, tiny_max):  # noqa: F811
+    """k_assemble (+ beta), k_relmap and -- with the tiny launch class on -- k_gemm_tiny from their own source; the
+    other steps by the emulator's loops: status, minor, factor and zero pattern of the reference"""
+    g = load_golden(name)
+    emu.emu_set_tuning(100, 1); emu.emu_set_tuning(14, tiny_max)
+    try:
+        st, minor, Lx, _ = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+    assert (st, minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-12
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+
+
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "lap3d_8_npd200", "tcov_r5lo", "lap2d_16_metis"])
+def test_wave_potrf_source_one_host_thread_per_lane(emu, name):  # noqa: F811
+    """k_potrf16 (one wave per diagonal block of <= 16 columns, registers + v_readlane only) from its own source with
+    one host thread per lane: factor, block inverse (the TRSM operand of the steps that follow) and the first bad
+    pivot of the not-positive-definite fixtures.  Slow (a readlane is two 64-thread barriers), hence few fixtures."""
+    g = load_golden(name)
+    emu.emu_set_tuning(100, 2); emu.emu_set_tuning(14, 4096)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+        if st == 0:
+            a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+            n, nrhs = g["B"].shape
+            X = np.ascontiguousarray(g["B"].T).reshape(-1).copy()
+            assert emu.emu_super_solve(1, *a, Lx, D, nrhs, X, n) == 0      # the solves run on the kernel's inverses
+            assert emu.emu_super_solve(0, *a, Lx, D, nrhs, X, n) == 0
+            assert relerr(X.reshape(nrhs, n).T, g["Z"]) < 1e-8
+    finally:
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+    assert (st, minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-12
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+
+
+@pytest.mark.parametrize("name", [n for n in tu.unsym_names() if "c10" not in n])
+def test_unsym_factorization_through_the_device_source(emu, name):  # noqa: F811
+    """k_assemble_aat<1> + k_add_beta<1> (stype == 0) from their own source"""
+    g = tu.load_unsym(name)
+    emu.emu_set_tuning(100, 1); emu.emu_set_tuning(14, 4096)
+    try:
+        st, minor, Lx = tu.emu_numeric_f(g)
+    finally:
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+    assert (st, minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-11
+
+
+def device_assemble(kind, g, Ap, Ai, Ax, F=None, iperm=None, beta=0.0, Anz=None, Fnz=None):
+    E = 2 if np.iscomplexobj(Ax) else 1
+    lib = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    lib.emu_device_assemble.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, i64p,
+                                        i64p, C.c_void_p, f64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_double, f64p]
+    flat = lambda x: np.ascontiguousarray(x, dtype=np.complex128).view(np.float64) if E == 2 else \
+        np.ascontiguousarray(x, dtype=np.float64)      # noqa: E731
+    keep = []
+
+    def ptr(a, dt=np.int64):
+        if a is None:
+            return None
+        keep.append(np.ascontiguousarray(a, dtype=dt))
+        return keep[-1].ctypes.data_as(C.c_void_p)
+    Lx = np.zeros(g["xsize"] * E)
+    fx = None
+    if F is not None:
+        keep.append(flat(F[2]))
+        fx = keep[-1].ctypes.data_as(C.c_void_p)
+    rc = lib.emu_device_assemble(kind, E, g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["xsize"],
+                                 np.ascontiguousarray(Ap, dtype=np.int64), np.ascontiguousarray(Ai, dtype=np.int64),
+                                 ptr(Anz), flat(Ax), ptr(F[0]) if F else None, ptr(F[1]) if F else None, ptr(Fnz), fx,
+                                 ptr(iperm), beta, Lx)
+    assert rc == 0
+    return Lx.view(np.complex128) if E == 2 else Lx
+
+
+def expected_panels(g, M):
+    """the supernodal layout filled from the dense matrix M (entries on or below the diagonal, pattern of L)"""
+    out = np.zeros(g["xsize"], dtype=M.dtype)
+    for s in range(g["nsuper"]):
+        k1, k2 = int(g["Super"][s]), int(g["Super"][s + 1])
+        rows = g["Ls"][int(g["Lpi"][s]):int(g["Lpi"][s + 1])]
+        P = M[np.ix_(rows, np.arange(k1, k2))].copy()
+        P[rows[:, None] < np.arange(k1, k2)[None, :]] = 0
+        out[int(g["Lpx"][s]):int(g["Lpx"][s + 1])] = P.T.reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("name", tu.unsym_names())
+@pytest.mark.parametrize("beta", [0.0, 0.75])
+def test_assemble_aat_source_real_and_complex(name, beta):
+    """k_assemble_aat<1> / <2> + k_add_beta: tril(A*F) + beta*I in the supernodal layout, against numpy; packed and
+    unpacked (Anz / Fnz with slack entries that must not be read)"""
+    import scipy.sparse as sp
+    g = tu.load_unsym(name)
+    S = sp.csc_matrix((g["Sx"], g["Si"], g["Sp"]), shape=(g["n"], g["ncol"]))
+    F = sp.csc_matrix((g["Fx"], g["Fi"], g["Fp"]), shape=(g["ncol"], g["n"]))
+    want = expected_panels(g, (S @ F).toarray() + beta * np.eye(g["n"]))
+    got = device_assemble(2, g, g["Sp"], g["Si"], g["Sx"], F=(g["Fp"], g["Fi"], g["Fx"]), beta=beta)
+    assert relerr(got, want) < 1e-14
+
+    def unpack(p, i, x):
+        cnt = np.diff(p)
+        p2 = np.concatenate([[0], np.cumsum(cnt + 2)]).astype(np.int64)
+        i2 = np.zeros(p2[-1], dtype=np.int64)
+        x2 = np.full(p2[-1], 1e30, dtype=x.dtype)
+        for k in range(len(cnt)):
+            i2[p2[k]:p2[k] + cnt[k]] = i[p[k]:p[k + 1]]
+            x2[p2[k]:p2[k] + cnt[k]] = x[p[k]:p[k + 1]]
+        return p2, i2, x2, cnt.astype(np.int64)
+    Sp, Si, Sx, Snz = unpack(g["Sp"], g["Si"], g["Sx"])
+    Fp, Fi, Fx, Fnz = unpack(g["Fp"], g["Fi"], g["Fx"])
+    got = device_assemble(2, g, Sp, Si, Sx, F=(Fp, Fi, Fx), beta=beta, Anz=Snz, Fnz=Fnz)
+    assert relerr(got, want) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["demo_c", "tcov_c30up", "tcov_z30lo", "helm3d_6_metis", "lap3d_8_metis", "tcov_ex5lo"])
+def test_assemble_sources_symmetric_real_and_complex(name):
+    """k_assemble / k_assemble_c on S = tril(PAP'), and k_assemble_perm<E> on A + the inverse permutation (entries that
+    cross the diagonal conjugated): the same panels"""
+    import scipy.sparse as sp
+    g = load_golden(name)
+    n = g["n"]
+    S = sp.csc_matrix((g["Sx"], g["Si"], g["Sp"]), shape=(n, n)).toarray()
+    beta = 0.5
+    want = expected_panels(g, np.tril(S) + beta * np.eye(n))
+    got = device_assemble(0, g, g["Sp"], g["Si"], g["Sx"], beta=beta)
+    assert np.array_equal(got, want)
+    # A itself (lower or upper stored) through the inverse permutation
+    A = sp.csc_matrix((g["Ax"], g["Ai"], g["Ap"]), shape=(n, n))
+    if g["stype"] > 0:
+        A = A.conj().T.tocsc()          # mi355_factor_set_matrix_perm takes the lower part
+    A = sp.tril(A, format="csc")
+    A.sort_indices()
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[g["Perm"]] = np.arange(n)
+    got = device_assemble(1, g, A.indptr.astype(np.int64), A.indices.astype(np.int64),
+                          np.asarray(A.data).astype(g["Sx"].dtype), iperm=iperm, beta=beta)
+    assert relerr(got, want) < 1e-15
