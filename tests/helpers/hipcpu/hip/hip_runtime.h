@@ -1,0 +1,147 @@
+// tests/helpers/hipcpu/hip/hip_runtime.h -- TEST INFRASTRUCTURE.
+// A stand-in for <hip/hip_runtime.h> that lets g++ compile the product's kernel sources
+// (suitesparse_amd/csrc/*.hip.hpp) UNCHANGED for execution on the CPU: one host thread per lane, 64 lanes per
+// wave, blockDim.x / 64 waves per workgroup.  Only what those kernels use exists here:
+//   threadIdx / blockIdx / blockDim, __shared__ (a function-local static: workgroups run one after the other),
+//   __syncthreads (a barrier over the workgroup's threads), v_readlane / readfirstlane / __shfl / __shfl_xor and
+//   v_mfma_f64_16x16x4_f64 (an exchange through per-wave arrays between two wave barriers), FP64 atomic add.
+// MFMA operand and result layout as the kernels assume it and the GPU runs confirmed it: lane l supplies
+// A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; lane l, register r holds D[i = (l >> 4) + 4 r][j = l & 15].
+// Never part of the product; the emulator (tests/helpers/sched_emu.cpp) is its only user.
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace hipcpu {
+struct Dim { unsigned x = 1, y = 1, z = 1; };
+struct Wave { pthread_barrier_t bar; int64_t slot[64]; double a[64], b[64]; };
+struct Block { pthread_barrier_t bar; Wave wave[16]; };
+extern thread_local Dim threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local Block *blk;         // null: the thread-by-thread mode (kernels without any cross-lane operation)
+extern thread_local Wave *wav;
+extern thread_local int lane;
+
+inline void syncthreads() { pthread_barrier_wait(&blk->bar); }
+inline int64_t exchange(int64_t v, int src)
+{
+    wav->slot[lane] = v;
+    pthread_barrier_wait(&wav->bar);
+    const int64_t r = wav->slot[src & 63];
+    pthread_barrier_wait(&wav->bar);
+    return r;
+}
+inline int readlane(int v, int src) { return (int)exchange(v, src); }
+inline int readfirstlane(int v) { return (int)exchange(v, 0); }           // full waves only
+template <class T> inline T shfl(T v, int src, int width = 64)
+{
+    static_assert(sizeof(T) <= 8, "shfl of at most 8 bytes");
+    int64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(T));
+    const int base = lane & ~(width - 1);
+    bits = exchange(bits, base + (src & (width - 1)));
+    T out;
+    std::memcpy(&out, &bits, sizeof(T));
+    return out;
+}
+template <class T> inline T shfl_xor(T v, int mask, int width = 64) { return shfl(v, (lane ^ mask), width); }
+
+typedef double v4d_t __attribute__((vector_size(32)));
+inline v4d_t mfma_f64_16x16x4(double a, double b, v4d_t c)
+{
+    wav->a[lane] = a; wav->b[lane] = b;
+    pthread_barrier_wait(&wav->bar);
+    const int j = lane & 15, l4 = lane >> 4;
+    for (int r = 0; r < 4; r++) {
+        const int i = l4 + 4 * r;
+        double s = c[r];
+        for (int k = 0; k < 4; k++) s += wav->a[k * 16 + i] * wav->b[k * 16 + j];
+        c[r] = s;
+    }
+    pthread_barrier_wait(&wav->bar);
+    return c;
+}
+inline double unsafeAtomicAdd(double *p, double v)
+{
+    // workgroups run one after the other, the threads of one concurrently: a CAS loop keeps the add atomic
+    uint64_t *q = reinterpret_cast<uint64_t *>(p);
+    uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), want;
+    double o;
+    do { std::memcpy(&o, &old, 8); const double n = o + v; std::memcpy(&want, &n, 8); }
+    while (!__atomic_compare_exchange_n(q, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return o;
+}
+inline int atomicMin(int *p, int v)
+{
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline int d2lo(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
+inline int d2hi(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline double hilo2d(int hi, int lo) { const int64_t b = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); double d; std::memcpy(&d, &b, 8); return d; }
+inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }
+
+// kernels without any cross-lane operation or barrier: thread after thread, no host threads needed
+template <class F> void launch_serial(int64_t grid, unsigned block, F call)
+{
+    blk = nullptr; wav = nullptr;
+    blockDim.x = block; gridDim.x = (unsigned)grid;
+    for (int64_t b = 0; b < grid; b++)
+        for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; lane = (int)(t & 63); call(); }
+}
+// any kernel: `block` host threads (a multiple of 64), each running its lane of workgroup 0, 1, 2, ... in turn
+template <class F> void launch(int64_t grid, unsigned block, F call)
+{
+    Block B;
+    const unsigned nw = block / 64;
+    pthread_barrier_init(&B.bar, nullptr, block);
+    for (unsigned w = 0; w < nw; w++) pthread_barrier_init(&B.wave[w].bar, nullptr, 64);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < block; t++)
+        th.emplace_back([&, t] {
+            blk = &B; wav = &B.wave[t / 64]; lane = (int)(t & 63);
+            blockDim.x = block; gridDim.x = (unsigned)grid; threadIdx.x = t;
+            for (int64_t b = 0; b < grid; b++) {
+                blockIdx.x = (unsigned)b;
+                call();
+                pthread_barrier_wait(&B.bar);       // the next workgroup reuses the __shared__ statics
+            }
+        });
+    for (auto &t : th) t.join();
+    pthread_barrier_destroy(&B.bar);
+    for (unsigned w = 0; w < nw; w++) pthread_barrier_destroy(&B.wave[w].bar);
+}
+}  // namespace hipcpu
+
+// HIP's global min / max overloads and double2
+#include <type_traits>
+template <class A, class B> inline typename std::common_type<A, B>::type min(A a, B b) { return b < a ? b : a; }
+template <class A, class B> inline typename std::common_type<A, B>::type max(A a, B b) { return a < b ? b : a; }
+struct double2 { double x, y; };
+inline double2 make_double2(double x, double y) { double2 v; v.x = x; v.y = y; return v; }
+
+using hipcpu::threadIdx; using hipcpu::blockIdx; using hipcpu::blockDim; using hipcpu::gridDim;
+using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define ext_vector_type(n) vector_size((n) * 8)
+#define __syncthreads() hipcpu::syncthreads()
+#define __builtin_amdgcn_readlane(v, l) hipcpu::readlane((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) hipcpu::readfirstlane((v))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_memtime() (0ULL)
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipcpu::mfma_f64_16x16x4((a), (b), (c))
+#define __shfl(...) hipcpu::shfl(__VA_ARGS__)
+#define __shfl_xor(...) hipcpu::shfl_xor(__VA_ARGS__)
+#define __double2loint(d) hipcpu::d2lo(d)
+#define __double2hiint(d) hipcpu::d2hi(d)
+#define __hiloint2double(hi, lo) hipcpu::hilo2d((hi), (lo))

@@ -3,6 +3,7 @@
 // very same task lists the HIP kernels consume, with plain loops, so that the HOST logic
 // (levels, task offsets, relative maps, truncated not-posdef rerun, solve sweeps) can be
 // checked against the oracle in the GPU-less container.  Never loaded by the product.
+#include "hip/hip_runtime.h"
 #include "../../suitesparse_amd/csrc/schedule.hpp"
 #include <cmath>
 #include <cstring>
@@ -10,82 +11,18 @@
 #include <algorithm>
 using namespace mi355;
 
-// ---- the product's host-runnable kernels (the marked region of kernels.hip.hpp, cut out by build() into
-// _host_kernels.inc), executed thread by thread: stand-ins for the handful of HIP names they use.  These kernels
-// have no barrier, no LDS and no wave intrinsic, so running their threads one after the other is exact.
-// The wave-runnable pieces (k_potrf16: v_readlane, nothing else) run with one host thread per lane; a readlane is two
-// barriers around a 64-entry exchange array, which is exact as long as the whole wave reaches it (it does: the only
-// early exit of k_potrf16 is wave-uniform).
-#include <pthread.h>
-#include <thread>
-namespace hostrun {
-struct Dim { unsigned x = 0, y = 0, z = 0; };
-thread_local Dim threadIdx, blockIdx, blockDim;
-inline double unsafeAtomicAdd(double *p, double v) { const double o = *p; *p += v; return o; }
-struct Wave { pthread_barrier_t bar; int slot[64]; };
-thread_local Wave *wave = nullptr;
-thread_local int lane_id = 0;
-inline int readlane(int v, int src)
-{
-    wave->slot[lane_id] = v;
-    pthread_barrier_wait(&wave->bar);
-    const int r = wave->slot[src];
-    pthread_barrier_wait(&wave->bar);
-    return r;
-}
-inline int double2loint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
-inline int double2hiint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
-inline double hiloint2double(int hi, int lo) { const int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &b, 8); return d; }
-inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }
-}
-#define __global__
-#define __device__
-#define __forceinline__ inline
-#define __launch_bounds__(...)
-#define __builtin_amdgcn_readlane hostrun::readlane
-#define __builtin_amdgcn_sched_barrier(x) ((void)0)
-#define __double2loint hostrun::double2loint
-#define __double2hiint hostrun::double2hiint
-#define __hiloint2double hostrun::hiloint2double
+// ---- the product's kernels, from their own source, on the CPU.  tests/helpers/hipcpu/hip/hip_runtime.h stands in for
+// the HIP header (the build puts it first on the include path), so kernels.hip.hpp compiles unchanged: kernels
+// without cross-lane operations run thread after thread (launch_serial), the others with one host thread per
+// lane (launch).  Emulator key 100: 1 = assembly, k_relmap, k_gemm_tiny; 2 = also k_potrf16; 3 = every kernel of
+// the real factorization (k_potrf64, k_trsm64, k_gemm64, k_gemm128) with the engine's launch geometry.
+namespace hipcpu { thread_local Dim threadIdx, blockIdx, blockDim, gridDim; thread_local Block *blk = nullptr; thread_local Wave *wav = nullptr; thread_local int lane = 0; }
+#include "../../suitesparse_amd/csrc/kernels.hip.hpp"
 namespace mi355 {
-using hostrun::threadIdx; using hostrun::blockIdx; using hostrun::blockDim; using hostrun::unsafeAtomicAdd; using hostrun::rsqrt;
-#include "_host_kernels.inc"
+#include "_host_kernels.inc"            // k_assemble_c, cut out of kernels_complex.hip.hpp by build()
 }
-#undef __global__
-#undef __device__
-#undef __forceinline__
-#undef __launch_bounds__
-#undef __builtin_amdgcn_readlane
-#undef __builtin_amdgcn_sched_barrier
-#undef __double2loint
-#undef __double2hiint
-#undef __hiloint2double
 namespace hostrun {
-// one host thread per lane, wave after wave
-template <class F> void launch_waves(int64_t grid, unsigned block, F kernel_call)
-{
-    for (int64_t b = 0; b < grid; b++)
-        for (unsigned w = 0; w < block / 64; w++) {
-            Wave ctx;
-            pthread_barrier_init(&ctx.bar, nullptr, 64);
-            std::vector<std::thread> th;
-            for (int l = 0; l < 64; l++)
-                th.emplace_back([&, l] {
-                    blockDim.x = block; blockIdx.x = (unsigned)b; threadIdx.x = w * 64 + l;
-                    wave = &ctx; lane_id = l;
-                    kernel_call();
-                });
-            for (auto &t : th) t.join();
-            pthread_barrier_destroy(&ctx.bar);
-        }
-}
-template <class F> void launch(int64_t grid, unsigned block, F kernel_call)
-{
-    blockDim.x = block;
-    for (int64_t b = 0; b < grid; b++)
-        for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; kernel_call(); }
-}
-int use_device_source = 0;              // emu_set_tuning(100, v): 1 = the thread-by-thread kernels, 2 = also the wave kernels
+int use_device_source = 0;
 }
 
 namespace {
@@ -119,12 +56,12 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
         // the engine's assembly launches (run_schedule), same arguments
         const int64_t grid = (ncols_asm + 255) / 256;
         if (Fp) {
-            hostrun::launch(grid, 256, [&] { k_assemble_aat<1>(ncols_asm, Ap, Ai, nullptr, Ax, Fp, Fi, nullptr, Fx, sc.supermap.data(),
+            hipcpu::launch_serial(grid, 256, [&] { k_assemble_aat<1>(ncols_asm, Ap, Ai, nullptr, Ax, Fp, Fi, nullptr, Fx, sc.supermap.data(),
                                                                  S.Super, S.Lpi, S.Lpx, ls32.data(), Lx, asm_mask); });
             if (beta != 0.0)
-                hostrun::launch(grid, 256, [&] { k_add_beta<1>(ncols_asm, beta, sc.supermap.data(), S.Super, S.Lpi, S.Lpx, Lx, asm_mask); });
+                hipcpu::launch_serial(grid, 256, [&] { k_add_beta<1>(ncols_asm, beta, sc.supermap.data(), S.Super, S.Lpi, S.Lpx, Lx, asm_mask); });
         } else {
-            hostrun::launch(grid, 256, [&] { k_assemble(ncols_asm, Ap, Ai, nullptr, Ax, sc.supermap.data(), S.Super, S.Lpi, S.Lpx,
+            hipcpu::launch_serial(grid, 256, [&] { k_assemble(ncols_asm, Ap, Ai, nullptr, Ax, sc.supermap.data(), S.Super, S.Lpi, S.Lpx,
                                                         ls32.data(), Lx, beta, asm_mask); });
         }
     }
@@ -157,7 +94,7 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
             rp[i].rm_off = sc.pairs[i].rm_off; rp[i].nsrow = sc.pairs[i].nsrow; rp[i].pad = 0;
         }
         int err = 0;
-        hostrun::launch((sc.relmap_size + 255) / 256, 256, [&] { k_relmap(sc.relmap_size, (int64_t)rp.size(), rp.data(), ls32.data(), relmap.data(), &err); });
+        hipcpu::launch_serial((sc.relmap_size + 255) / 256, 256, [&] { k_relmap(sc.relmap_size, (int64_t)rp.size(), rp.data(), ls32.data(), relmap.data(), &err); });
         if (err) { info[S.nsuper + 1] = -1; return; }
     } else
     for (const UpdatePair &u : sc.pairs)
@@ -168,12 +105,24 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
         const Step &st = sc.steps[(size_t)si];
         if (st.kind == STEP_POTRF) {
             std::vector<int64_t> todo;
-            if (hostrun::use_device_source >= 2 && !sc.potrf_order.empty()) {
+            if (hostrun::use_device_source >= 3) {
+                // exactly the engine's POTRF launches (run_schedule)
+                if (!sc.potrf_order.empty()) {
+                    const int32_t *ord = sc.potrf_order.data() + st.first;
+                    if (st.nsmall > 0)
+                        hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
+                            k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
+                    if (st.count > st.nsmall)
+                        hipcpu::launch(st.count - st.nsmall, 256, [&] {
+                            k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), ord + st.nsmall); });
+                } else
+                    hipcpu::launch(st.count, 256, [&] { k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), nullptr); });
+            } else if (hostrun::use_device_source >= 2 && !sc.potrf_order.empty()) {
                 // the engine's launches: k_potrf16 (from its own source) over the first nsmall entries of the order
                 // list, the wider blocks by the loops below
                 const int32_t *ord = sc.potrf_order.data() + st.first;
                 if (st.nsmall > 0)
-                    hostrun::launch_waves((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
+                    hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
                         k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
                 for (int64_t k = st.nsmall; k < st.count; k++) todo.push_back(st.first + ord[k]);
             } else
@@ -201,9 +150,20 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                     for (int i = 0; i < nb; i++) D[i + c * nb] = (i >= c) ? x[i] : 0.0;
                 }
             }
+        } else if (hostrun::use_device_source >= 3 && !(st.flags & STEP_TINY)) {
+            // exactly the engine's GEMM launches of a real factor
+            const GemmTask *tk = sc.gemm.data() + st.first;
+            const Schedule::TileEntry *tm = sc.gemm_tile_tab.data() + st.tmap_off;
+            if (st.big)
+                hipcpu::launch(st.ntiles, 256, [&] { k_gemm128<false>(tk, tm, Lx, Dinv.data(), relmap.data(), (unsigned long long *)nullptr); });
+            else if (st.trsm)
+                hipcpu::launch(st.ntiles, 256, [&] { k_trsm64(tk, tm, Lx, Dinv.data()); });
+            else
+                hipcpu::launch(st.ntiles, 256, [&] { k_gemm64(tk, tm, Lx, Dinv.data(), relmap.data()); });
+            if (!check_tile_table(sc, st)) info[S.nsuper + 1] = -1;
         } else if (dev && (st.flags & STEP_TINY)) {
             // the engine's k_gemm_tiny launch of this step
-            hostrun::launch((st.ntiles + TINY_WAVES - 1) / TINY_WAVES, 64 * TINY_WAVES, [&] {
+            hipcpu::launch_serial((st.ntiles + TINY_WAVES - 1) / TINY_WAVES, 64 * TINY_WAVES, [&] {
                 k_gemm_tiny(sc.gemm.data() + st.first, sc.gemm_tile_tab.data() + st.tmap_off, st.ntiles, Lx, relmap.data()); });
             if (!check_tile_table(sc, st)) info[S.nsuper + 1] = -1;
         } else {
@@ -295,21 +255,21 @@ int emu_device_assemble(int kind, int E, int64_t n, int64_t nsuper, const int64_
     const int64_t grid = (n + 255) / 256;
     const int8_t *nomask = nullptr;
     if (kind == 0 && E == 1)
-        hostrun::launch(grid, 256, [&] { k_assemble(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
     else if (kind == 0)
-        hostrun::launch(grid, 256, [&] { k_assemble_c(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_c(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
     else if (kind == 1 && E == 1)
-        hostrun::launch(grid, 256, [&] { k_assemble_perm<1>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<1>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 1)
-        hostrun::launch(grid, 256, [&] { k_assemble_perm<2>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<2>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 2 && E == 1)
-        hostrun::launch(grid, 256, [&] { k_assemble_aat<1>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_aat<1>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 2)
-        hostrun::launch(grid, 256, [&] { k_assemble_aat<2>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_aat<2>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else return -1;
     if (kind != 0 && beta != 0.0) {
-        if (E == 1) hostrun::launch(grid, 256, [&] { k_add_beta<1>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
-        else hostrun::launch(grid, 256, [&] { k_add_beta<2>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
+        if (E == 1) hipcpu::launch_serial(grid, 256, [&] { k_add_beta<1>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
+        else hipcpu::launch_serial(grid, 256, [&] { k_add_beta<2>(n, beta, supermap.data(), Super, Lpi, Lpx, Lx, nomask); });
     }
     return 0;
 }

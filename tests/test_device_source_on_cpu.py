@@ -163,3 +163,100 @@ def test_assemble_sources_symmetric_real_and_complex(name):
     got = device_assemble(1, g, A.indptr.astype(np.int64), A.indices.astype(np.int64),
                           np.asarray(A.data).astype(g["Sx"].dtype), iperm=iperm, beta=beta)
     assert relerr(got, want) < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Every kernel of the real factorization from its own source (emulator key 100 = 3): k_potrf64, k_trsm64, k_gemm64,
+# k_gemm128 compiled by g++ against tests/helpers/hipcpu/hip/hip_runtime.h (one host thread per lane; __syncthreads,
+# v_readlane and v_mfma_f64_16x16x4_f64 as barriers around exchange arrays) and launched with the engine's geometry.
+# Slow (a 256-thread barrier per __syncthreads), so the cases are small -- but they are the MFMA / LDS kernels.
+
+def dense_problem(n, seed=None):
+    rng = np.random.default_rng(n if seed is None else seed)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    g = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n], dtype=np.int64),
+             Lpi=np.array([0, n], dtype=np.int64), Lpx=np.array([0, n * n], dtype=np.int64),
+             Ls=np.arange(n, dtype=np.int64), Sp=np.arange(n + 1, dtype=np.int64) * n,
+             Si=np.tile(np.arange(n, dtype=np.int64), n), Sx=np.ascontiguousarray(A.T).reshape(-1), beta=0.0)
+    return g, A
+
+
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "tcov_r5lo", "tcov_ex5lo", "tcov_20lo", "demo_bcsstk02"])
+def test_all_factor_kernels_from_source_golden(emu, name):  # noqa: F811
+    g = load_golden(name)
+    emu.emu_set_tuning(100, 3)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(100, 0)
+    assert (st, minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-10                 # the GPU parity bar (TRSM by explicit block inverses)
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+
+
+@pytest.mark.parametrize("n,ob,ob2,negate", [(330, 128, 0, None), (200, 64, 128, None), (150, 64, 0, 97)])
+def test_dense_supernode_through_the_mfma_kernels(emu, n, ob, ob2, negate):  # noqa: F811
+    """one dense supernode: k_potrf64 (all four 16-column blocks, the MFMA assembly of the inverse), k_trsm64, the
+    K = 64 updates in k_gemm64 and -- n = 330: M = 202 >= 192, N >= 96 -- the outer update in k_gemm128 (DIRECT_SUB
+    epilogue, ragged edges); negate: a bad pivot in the middle, LAPACK's info from k_potrf64"""
+    from oracle import port
+    g, A = dense_problem(n)
+    if negate is not None:
+        g["Sx"] = g["Sx"].copy()
+        g["Sx"][negate * n + negate] = -1.0
+    g["maxcsize"] = 1
+    emu.emu_set_tuning(100, 3); emu.emu_set_tuning(2, ob); emu.emu_set_tuning(7, ob2)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert (st, minor) == (so, mo)
+    low = np.tril(np.ones((n, n), dtype=bool)).T.reshape(-1)       # column-major: entries on or below the diagonal
+    assert relerr(Lx[low], Lo[low]) < 1e-10
+    if st == 1:
+        assert np.array_equal(Lx[low] == 0, Lo[low] == 0)
+
+
+def test_scatter_update_through_k_gemm128(emu):  # noqa: F811
+    """two supernodes, the first one's rows scattered with gaps over the second: the update task is big enough for
+    k_gemm128 (M = 230, N = 230, K = 96), i.e. its SCATTER_SUB epilogue -- the relative map staged in LDS, FP64
+    atomics -- plus k_relmap, from their own source"""
+    from oracle import port
+    n0, n1 = 96, 340
+    n = n0 + n1
+    extra = np.array(sorted(set(range(n0, n, 3)) | set(range(n0 + 1, n, 3)) | {n - 1}), dtype=np.int64)
+    rows0 = np.concatenate([np.arange(n0), extra])
+    g = dict(n=n, nsuper=2, Super=np.array([0, n0, n], dtype=np.int64),
+             Lpi=np.array([0, len(rows0), len(rows0) + n1], dtype=np.int64),
+             Lpx=np.array([0, len(rows0) * n0, len(rows0) * n0 + n1 * n1], dtype=np.int64),
+             Ls=np.concatenate([rows0, np.arange(n0, n)]).astype(np.int64), beta=0.0)
+    g["ssize"], g["xsize"], g["maxcsize"] = len(g["Ls"]), int(g["Lpx"][-1]), len(extra) ** 2
+    assert len(extra) >= 192
+    rng = np.random.default_rng(7)
+    A = np.zeros((n, n))
+    A[np.ix_(rows0, np.arange(n0))] = rng.standard_normal((len(rows0), n0))
+    A[n0:, n0:] = rng.standard_normal((n1, n1))
+    A = np.tril(A)
+    A = A + A.T + np.eye(n) * (np.abs(A + A.T).sum(1).max() + 1)
+    import scipy.sparse as sp
+    S = sp.csc_matrix(np.tril(A))
+    S.sort_indices()
+    g.update(Sp=S.indptr.astype(np.int64), Si=S.indices.astype(np.int64), Sx=S.data)
+    cls = np.zeros(8, dtype=np.int64)
+    emu.emu_set_tuning(100, 3)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(100, 0)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert (st, minor) == (so, mo) == (0, n)
+    # compare on the lower trapezoid of each panel (the upper corner of a panel's diagonal block is not defined)
+    for s in range(2):
+        a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+        nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+        got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+        low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+        assert relerr(got[low], want[low]) < 1e-10
