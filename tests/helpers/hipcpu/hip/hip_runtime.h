@@ -94,7 +94,7 @@ template <class F> void launch_serial(int64_t grid, unsigned block, F call)
         for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; lane = (int)(t & 63); call(); }
 }
 // any kernel: `block` host threads (a multiple of 64), each running its lane of workgroup 0, 1, 2, ... in turn
-template <class F> void launch(int64_t grid, unsigned block, F call)
+template <class F> void launch(int64_t grid, unsigned block, F call, unsigned grid_y = 1)
 {
     Block B;
     const unsigned nw = block / 64;
@@ -104,12 +104,14 @@ template <class F> void launch(int64_t grid, unsigned block, F call)
     for (unsigned t = 0; t < block; t++)
         th.emplace_back([&, t] {
             blk = &B; wav = &B.wave[t / 64]; lane = (int)(t & 63);
-            blockDim.x = block; gridDim.x = (unsigned)grid; threadIdx.x = t;
-            for (int64_t b = 0; b < grid; b++) {
-                blockIdx.x = (unsigned)b;
-                call();
-                pthread_barrier_wait(&B.bar);       // the next workgroup reuses the __shared__ statics
-            }
+            blockDim.x = block; gridDim.x = (unsigned)grid; gridDim.y = grid_y; threadIdx.x = t;
+            for (unsigned by = 0; by < grid_y; by++)
+                for (int64_t b = 0; b < grid; b++) {
+                    blockIdx.x = (unsigned)b; blockIdx.y = by;
+                    call();
+                    pthread_barrier_wait(&B.bar);   // the next workgroup reuses the __shared__ statics
+                }
+            blockIdx.y = 0;
         });
     for (auto &t : th) t.join();
     pthread_barrier_destroy(&B.bar);

@@ -18,6 +18,7 @@ using namespace mi355;
 // the real factorization (k_potrf64, k_trsm64, k_gemm64, k_gemm128) with the engine's launch geometry.
 namespace hipcpu { thread_local Dim threadIdx, blockIdx, blockDim, gridDim; thread_local Block *blk = nullptr; thread_local Wave *wav = nullptr; thread_local int lane = 0; }
 #include "../../suitesparse_amd/csrc/kernels.hip.hpp"
+#include "../../suitesparse_amd/csrc/solve_kernels.hip.hpp"
 namespace mi355 {
 #include "_host_kernels.inc"            // k_assemble_c, cut out of kernels_complex.hip.hpp by build()
 }
@@ -634,6 +635,130 @@ int emu_partition_plan(int64_t n, int64_t nsuper, const int64_t *Super, const in
     for (const BcastPoint &b : dst.bcasts) { out[6] += (double)b.count; if (b.root == rank) out[7] += (double)b.count; }
     out[8] = count(dst, STEP_GEMM);
     out[9] = (double)loc.steps.size();
+    return 0;
+}
+
+// The sweeps of a real factor with the product's solve kernels from their own source: the launch sequence of the engine's
+// solve_dev (engine.hip) -- grouped scalar kernels (mma = 0, nrhs <= SOLVE_NR, group != 0), grouped MFMA kernels
+// (mma != 0, group != 0), or one diagonal + one update launch per block (group = 0; scalar: any nrhs).  X: n x nrhs,
+// column-major, leading dimension d.  Lx / Dinv: a factor and its block inverses (emu_super_numeric).
+int emu_device_solve(int lower, int mma, int group, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                     const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
+                     const double *Dinv, int64_t nrhs, double *X, int64_t d)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    SolveSchedule ss; build_solve_groups(sc, ss);
+    if (!check_schedule_bounds(S, sc, &ss).empty()) return -40;
+    if (n == 0 || nrhs == 0) return 0;
+    std::vector<int32_t> ls32((size_t)Lpi[nsuper] + 1);
+    for (int64_t i = 0; i < Lpi[nsuper]; i++) ls32[i] = (int32_t)Ls[i];
+    const int nr = (int)nrhs, nrr = nr;
+    const PotrfTask *P = sc.potrf.data();
+    const int32_t *dLs = ls32.data();
+    double *const Xcol = X; const int64_t dcol = d;
+    std::vector<double> yrow;
+    if (!mma && group && nr > SOLVE_NR) return -41;
+    if (!mma && group) {
+        for (size_t ii = 0; ii < ss.steps.size(); ii++) {
+            const SolveStep &st = ss.steps[lower ? ii : ss.steps.size() - 1 - ii];
+            if (st.gcount <= 0) continue;
+            const SolveGroupTask *gp = ss.groups.data() + st.gfirst;
+            auto group_kernel = [&]() {
+#define EMU_SG(T, NRT, MB) hipcpu::launch(st.gcount, 256, [&] { k_solve_group<T, NRT, MB>(gp, Dinv, Lx, X, d, nr); })
+#define EMU_SG_MB(T, NRT) do { if (st.maxblk <= 1) EMU_SG(T, NRT, 1); else if (st.maxblk <= 2) EMU_SG(T, NRT, 2); else EMU_SG(T, NRT, SOLVE_GROUP); } while (0)
+                if (lower) { if (nr == 1) EMU_SG_MB(false, 1); else EMU_SG_MB(false, SOLVE_NR); }
+                else       { if (nr == 1) EMU_SG_MB(true, 1); else EMU_SG_MB(true, SOLVE_NR); }
+#undef EMU_SG_MB
+#undef EMU_SG
+            };
+            if (lower) {
+                group_kernel();
+                if (st.stiles > 0)
+                    hipcpu::launch(st.stiles, 256, [&] { k_solve_fwd_update(ss.utasks.data() + st.ufirst, ss.tile_task.data() + st.tmap_off, Lx, dLs, X, d, nr); });
+            } else {
+                if (st.rcount > 0) {
+                    if (nr == 1) hipcpu::launch(st.rcount, 256, [&] { k_solve_bwd_range<1>(ss.utasks.data() + st.ufirst, ss.ranges.data() + st.rfirst, Lx, dLs, X, d, nr); });
+                    else hipcpu::launch(st.rcount, 256, [&] { k_solve_bwd_range<SOLVE_NR>(ss.utasks.data() + st.ufirst, ss.ranges.data() + st.rfirst, Lx, dLs, X, d, nr); });
+                }
+                group_kernel();
+            }
+        }
+        return 0;
+    }
+    if (mma) {
+        const int64_t ldr = ((int64_t)nrr + 15) & ~(int64_t)15;
+        yrow.assign((size_t)n * (size_t)ldr, 0.0);
+        hipcpu::launch((n + 63) / 64, 256, [&] { k_solve_transpose<double>(n, nr, Xcol, dcol, yrow.data(), ldr, 1); });
+        X = yrow.data(); d = ldr;
+    }
+    if (mma && group) {
+        for (size_t ii = 0; ii < ss.steps.size(); ii++) {
+            const SolveStep &st = ss.steps[lower ? ii : ss.steps.size() - 1 - ii];
+            if (st.gcount <= 0) continue;
+            const SolveGroupTask *gp = ss.groups.data() + st.gfirst;
+            const unsigned gy = (unsigned)((nrr + SG_CW - 1) / SG_CW);
+            auto group_kernel = [&]() {
+#define EMU_SGM(T, MB) hipcpu::launch(st.gcount, 256, [&] { k_solve_group_mma<T, 1, MB>(gp, Dinv, Lx, X, d, nrr); }, gy)
+#define EMU_SGM_MB(T) do { if (st.maxblk <= 1) EMU_SGM(T, 1); else if (st.maxblk <= 2) EMU_SGM(T, 2); else EMU_SGM(T, SOLVE_GROUP); } while (0)
+                if (lower) EMU_SGM_MB(false); else EMU_SGM_MB(true);
+#undef EMU_SGM_MB
+#undef EMU_SGM
+            };
+            const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_fwd_div_mma)));
+            const int64_t grid = (st.stiles + grp - 1) / grp;
+            if (lower) {
+                group_kernel();
+                if (st.stiles > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch(grid, 256, [&] { k_solve_fwd_mma<1>(ss.utasks.data() + st.ufirst, ss.tile_task.data() + st.tmap_off, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+            } else {
+                if (st.rmcount > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch(st.rmcount, 256, [&] { k_solve_bwd_mma_run<1>(ss.utasks.data() + st.ufirst, ss.ranges_mma.data() + st.rmfirst, Lx, dLs, X, d, nrr, j0); });
+                group_kernel();
+            }
+        }
+    } else if (lower) {
+        for (const Step &st : sc.steps) {
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            if (mma) hipcpu::launch(st.count, 256, [&] { k_solve_diag_mma<false, 1>(P + st.first, Dinv, X, d, nrr); });
+            else hipcpu::launch(st.count, 256, [&] { k_solve_diag<false>(P + st.first, Dinv, X, d, nr); });
+            if (st.stiles > 0) {
+                const int32_t *tm = sc.solve_tile_task.data() + st.tmap_off;
+                if (mma) {
+                    const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch((st.stiles + grp - 1) / grp, 256, [&] { k_solve_fwd_mma<1>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+                } else
+                    hipcpu::launch(st.stiles, 256, [&] { k_solve_fwd_update(P + st.first, tm, Lx, dLs, X, d, nr); });
+            }
+        }
+    } else {
+        for (size_t i = sc.steps.size(); i-- > 0;) {
+            const Step &st = sc.steps[i];
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            if (st.stiles > 0) {
+                const int32_t *tm = sc.solve_tile_task.data() + st.tmap_off;
+                if (mma) {
+                    const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch((st.stiles + grp - 1) / grp, 256, [&] { k_solve_bwd_mma<1>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+                } else if (nr <= SOLVE_NR) {
+                    const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 128));
+                    const int64_t grid = (st.stiles + grp - 1) / grp;
+                    if (nr == 1) hipcpu::launch(grid, 256, [&] { k_solve_bwd_update<1>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nr); });
+                    else hipcpu::launch(grid, 256, [&] { k_solve_bwd_update<SOLVE_NR>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nr); });
+                } else
+                    hipcpu::launch(st.stiles, 256, [&] { k_solve_bwd_update<0>(P + st.first, tm, st.stiles, 1, Lx, dLs, X, d, nr); });
+            }
+            if (mma) hipcpu::launch(st.count, 256, [&] { k_solve_diag_mma<true, 1>(P + st.first, Dinv, X, d, nrr); });
+            else hipcpu::launch(st.count, 256, [&] { k_solve_diag<true>(P + st.first, Dinv, X, d, nr); });
+        }
+    }
+    if (mma)
+        hipcpu::launch((n + 63) / 64, 256, [&] { k_solve_transpose<double>(n, nr, Xcol, dcol, yrow.data(), d, 0); });
     return 0;
 }
 }

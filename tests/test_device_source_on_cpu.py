@@ -260,3 +260,49 @@ def test_scatter_update_through_k_gemm128(emu):  # noqa: F811
         got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
         low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
         assert relerr(got[low], want[low]) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The solve kernels from their own source: emu_device_solve issues the launch sequence of the engine's solve_dev
+# (grouped scalar sweeps, grouped MFMA sweeps over the row-major image, one launch pair per block) on the CPU.
+
+def device_solve(emu, g, Lx, D, B, mma, group):  # noqa: F811
+    emu.emu_device_solve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64,
+                                     C.c_int64, f64p, f64p, C.c_int64, f64p, C.c_int64]
+    a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+    n, nrhs = B.shape
+    X = np.ascontiguousarray(B.T).reshape(-1).copy()
+    assert emu.emu_device_solve(1, mma, group, *a, Lx, D, nrhs, X, n) == 0
+    Y = X.reshape(nrhs, n).T.copy()
+    assert emu.emu_device_solve(0, mma, group, *a, Lx, D, nrhs, X, n) == 0
+    return Y, X.reshape(nrhs, n).T.copy()
+
+
+PATHS = [(0, 1, 1), (0, 1, 4), (0, 0, 1), (0, 0, 6), (1, 1, 5), (1, 0, 9), (1, 1, 70)]      # (mma, grouped, nrhs)
+
+
+@pytest.mark.parametrize("mma,group,nrhs", PATHS)
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "tcov_r5lo", "lap2d_16_metis"])
+def test_solve_kernels_from_source_golden(emu, name, mma, group, nrhs):  # noqa: F811
+    from oracle import port
+    g = load_golden(name)
+    st, minor, Lx, D = run_emu(emu, g)
+    B = np.random.default_rng(nrhs).standard_normal((g["n"], nrhs))
+    Yo = port.super_solve(g, g["Lx"], B, lower=True)
+    Xo = port.super_solve(g, g["Lx"], Yo, lower=False)
+    Y, X = device_solve(emu, g, Lx, D, B, mma, group)
+    assert relerr(Y, Yo) < 1e-9 and relerr(X, Xo) < 1e-9
+
+
+@pytest.mark.parametrize("mma,group,nrhs", [(0, 1, 1), (0, 1, 3), (1, 1, 8), (0, 0, 2), (1, 0, 5)])
+def test_solve_kernels_from_source_wide_supernode(emu, mma, group, nrhs):  # noqa: F811
+    """one dense supernode of 330 columns: a full solve group of four 64-column blocks plus a second group, row tiles
+    below the groups, the backward runs"""
+    g, A = dense_problem(330)
+    st, minor, Lx, D = run_emu(emu, g)
+    assert st == 0
+    B = np.random.default_rng(nrhs).standard_normal((330, nrhs))
+    Y, X = device_solve(emu, g, Lx, D, B, mma, group)
+    Lc = np.linalg.cholesky(A)
+    assert relerr(Y, np.linalg.solve(Lc, B)) < 1e-9
+    assert relerr(X, np.linalg.solve(A, B)) < 1e-9
