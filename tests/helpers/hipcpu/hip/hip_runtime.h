@@ -49,7 +49,11 @@ template <class T> inline T shfl(T v, int src, int width = 64)
 }
 template <class T> inline T shfl_xor(T v, int mask, int width = 64) { return shfl(v, (lane ^ mask), width); }
 
+#ifdef __clang__
+typedef double v4d_t __attribute__((ext_vector_type(4)));      // clang: the kernels' own vector types, swizzles included
+#else
 typedef double v4d_t __attribute__((vector_size(32)));
+#endif
 inline v4d_t mfma_f64_16x16x4(double a, double b, v4d_t c)
 {
     wav->a[lane] = a; wav->b[lane] = b;
@@ -134,7 +138,9 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static
-#define ext_vector_type(n) vector_size((n) * 8)
+#ifndef __clang__
+#define ext_vector_type(n) vector_size((n) * 8)                // g++: no .x/.y swizzles (kernels_complex needs clang)
+#endif
 #define __syncthreads() hipcpu::syncthreads()
 #define __builtin_amdgcn_readlane(v, l) hipcpu::readlane((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) hipcpu::readfirstlane((v))

@@ -19,9 +19,13 @@ using namespace mi355;
 namespace hipcpu { thread_local Dim threadIdx, blockIdx, blockDim, gridDim; thread_local Block *blk = nullptr; thread_local Wave *wav = nullptr; thread_local int lane = 0; }
 #include "../../suitesparse_amd/csrc/kernels.hip.hpp"
 #include "../../suitesparse_amd/csrc/solve_kernels.hip.hpp"
+#ifdef __clang__
+#include "../../suitesparse_amd/csrc/kernels_complex.hip.hpp"      // uses clang's vector swizzles
+#else
 namespace mi355 {
-#include "_host_kernels.inc"            // k_assemble_c, cut out of kernels_complex.hip.hpp by build()
+#include "_host_kernels.inc"            // g++: only k_assemble_c, cut out of kernels_complex.hip.hpp by build()
 }
+#endif
 namespace hostrun {
 int use_device_source = 0;
 }
@@ -761,4 +765,76 @@ int emu_device_solve(int lower, int mma, int group, int64_t n, int64_t nsuper, c
         hipcpu::launch((n + 63) / 64, 256, [&] { k_solve_transpose<double>(n, nr, Xcol, dcol, yrow.data(), d, 0); });
     return 0;
 }
+
+#ifdef __clang__
+// A complex (interleaved) factorization entirely by the product's kernels from their own source: k_assemble_c, k_relmap,
+// k_potrf64c, k_gemm64c (small tasks and TRSM) and k_gemm128<true> (big tasks through the real view), with the engine's
+// launch sequence (run_schedule) and its not-positive-definite protocol (mi355_factor_numeric).  Ax, Lx: E = 2.
+int emu_device_numeric_c(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                         const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
+                         const double *Ax, double beta, int quick, double *Lx, int64_t *minor, int *status, int64_t *nbig)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls; S.cplx = true;
+    if (!validate_symbolic(S).empty()) return -4;
+    std::vector<int32_t> ls32((size_t)Lpi[nsuper] + 1);
+    for (int64_t i = 0; i < Lpi[nsuper]; i++) ls32[i] = (int32_t)Ls[i];
+    std::vector<int> info;
+    std::vector<double> Dinv;
+    int64_t big_launches = 0;
+    auto run_c = [&](const Schedule &sc, int64_t ncols_asm) -> int {
+        if (!check_schedule_bounds(S, sc).empty()) return -10;
+        std::fill(Lx, Lx + 2 * xsize, 0.0);
+        info.assign(nsuper + 2, 0);
+        Dinv.assign(2 * (size_t)sc.dinv_size + 2, 0.0);
+        const int8_t *nomask = nullptr;
+        if (ncols_asm > 0)
+            hipcpu::launch_serial((ncols_asm + 255) / 256, 256, [&] { k_assemble_c(ncols_asm, Ap, Ai, nullptr, Ax, sc.supermap.data(), Super, Lpi, Lpx,
+                                                                                   ls32.data(), Lx, beta, nomask); });
+        std::vector<int32_t> relmap(sc.relmap_size + 1);
+        if (sc.relmap_size > 0) {
+            std::vector<RelmapPair> rp(sc.pairs.size());
+            for (size_t i = 0; i < rp.size(); i++) {
+                rp[i].ls_src = sc.pairs[i].ls_src; rp[i].ls_dst = sc.pairs[i].ls_dst;
+                rp[i].rm_off = sc.pairs[i].rm_off; rp[i].nsrow = sc.pairs[i].nsrow; rp[i].pad = 0;
+            }
+            int err = 0;
+            hipcpu::launch_serial((sc.relmap_size + 255) / 256, 256, [&] { k_relmap(sc.relmap_size, (int64_t)rp.size(), rp.data(), ls32.data(), relmap.data(), &err); });
+            if (err) return -11;
+        }
+        for (const Step &st : sc.steps) {
+            if (st.count <= 0) continue;
+            if (st.kind == STEP_POTRF) {
+                hipcpu::launch(st.count, 256, [&] { k_potrf64c(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data()); });
+            } else {
+                const GemmTask *tk = sc.gemm.data() + st.first;
+                const Schedule::TileEntry *tm = sc.gemm_tile_tab.data() + st.tmap_off;
+                if (st.big) {
+                    hipcpu::launch(st.ntiles, 256, [&] { k_gemm128<true>(tk, tm, Lx, Dinv.data(), relmap.data(), (unsigned long long *)nullptr); });
+                    big_launches++;
+                } else
+                    hipcpu::launch(st.ntiles, 256, [&] { k_gemm64c(tk, tm, Lx, Dinv.data(), relmap.data()); });
+                if (!check_tile_table(sc, st)) return -12;
+            }
+        }
+        return 0;
+    };
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    if (int rc = run_c(sc, n)) return rc;
+    *status = 0; *minor = n;
+    int64_t sf = -1;
+    for (int64_t s = 0; s < nsuper; s++) if (info[s]) { sf = s; break; }
+    if (sf >= 0) {
+        const int inf = info[sf];
+        *status = 1; *minor = Super[sf] + inf - 1;
+        const int64_t nscol2 = (inf == 1 || quick) ? 0 : inf - 1;
+        Schedule tr; build_schedule(S, sf, nscol2, tr);
+        if (int rc = run_c(tr, nscol2 > 0 ? Super[sf + 1] : Super[sf])) return rc;
+        const int64_t nsrow = Lpi[sf + 1] - Lpi[sf], tail = Lpx[sf] + nsrow * nscol2;
+        std::fill(Lx + 2 * tail, Lx + 2 * xsize, 0.0);
+    }
+    if (nbig) *nbig = big_launches;
+    return 0;
+}
+#endif
 }

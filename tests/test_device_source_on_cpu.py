@@ -306,3 +306,57 @@ def test_solve_kernels_from_source_wide_supernode(emu, mma, group, nrhs):  # noq
     Lc = np.linalg.cholesky(A)
     assert relerr(Y, np.linalg.solve(Lc, B)) < 1e-9
     assert relerr(X, np.linalg.solve(A, B)) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The complex kernels (cd_ / zd_ instantiations of the reference) from their own source: k_assemble_c, k_potrf64c,
+# k_gemm64c and k_gemm128<true> (big tasks through the real view).  Needs the emulator built with clang++ (the
+# complex kernels use its vector swizzles); build() does that where /opt/rocm's clang++ exists.
+
+def device_numeric_c(g, quick=0):
+    lib = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    if not hasattr(lib, "emu_device_numeric_c"):
+        pytest.skip("emulator built without clang++")
+    lib.emu_device_numeric_c.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p, i64p,
+                                         f64p, C.c_double, C.c_int, f64p, i64p, C.POINTER(C.c_int), i64p]
+    Lx = np.zeros(2 * g["xsize"])
+    minor, st, nbig = np.zeros(1, dtype=np.int64), C.c_int(0), np.zeros(1, dtype=np.int64)
+    rc = lib.emu_device_numeric_c(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"],
+                                  g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.complex128).view(np.float64),
+                                  g["beta"], quick, Lx, minor, C.byref(st), nbig)
+    assert rc == 0
+    return st.value, int(minor[0]), Lx.view(np.complex128), int(nbig[0])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if load_golden(n)["xtype"] == 2 and n != "helm3d_6_metis"])
+def test_complex_kernels_from_source_golden(name):
+    g = load_golden(name)
+    st, minor, Lx, _ = device_numeric_c(g)
+    assert (st, minor) == (g["status"], g["minor"])
+    assert relerr(Lx, g["Lx"]) < 1e-10
+    if st == 1:
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+
+
+def test_complex_big_tile_kernel_from_source():
+    """a dense Hermitian supernode of 250 columns with 128-wide outer blocks: the outer update (M = N = 122 complex
+    rows = 244 real ones, K = 128) runs in k_gemm128<true> -- the interleaved real view, the pair images of B built at
+    the LDS write, the rectangular 64 x 128 tile table"""
+    from oracle import port
+    n = 250
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = M @ M.conj().T + n * np.eye(n)
+    g = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n], dtype=np.int64),
+             Lpi=np.array([0, n], dtype=np.int64), Lpx=np.array([0, n * n], dtype=np.int64),
+             Ls=np.arange(n, dtype=np.int64), Sp=np.arange(n + 1, dtype=np.int64) * n,
+             Si=np.tile(np.arange(n, dtype=np.int64), n), Sx=np.ascontiguousarray(A.T).reshape(-1), beta=0.0, maxcsize=1)
+    lib = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    lib.emu_set_tuning(2, 128); lib.emu_set_tuning(7, 0)
+    try:
+        st, minor, Lx, nbig = device_numeric_c(g)
+    finally:
+        lib.emu_set_tuning(2, 256); lib.emu_set_tuning(7, 1024)
+    assert (st, minor) == (0, n) and nbig >= 1
+    Lg = Lx.reshape(n, n).T
+    assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
