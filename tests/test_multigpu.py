@@ -518,3 +518,57 @@ def test_two_process_gloo_run(tmp_path):
         st, worst, st2, minor2, so2, mo2 = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7])
         assert st == 0 and worst < 1e-11
         assert st2 == so2 == 1 and minor2 == mo2
+
+
+WORKER_DEVICE_SOURCE = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+import test_multigpu as tm
+from suitesparse_amd import multigpu
+from oracle import port
+g = tm.problem("lap3d", 6)
+f = tm.EmuFactor(g)
+f.E.emu_set_tuning(100, 3)              # every factor kernel from the product's own source (one host thread per lane)
+run = multigpu.PartitionedFactor(f, g, rank, world, min_subtrees_per_rank=1)
+assert run.dist and run.reduce is not None
+st = run.numeric()
+so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+owner = run.part["owner"]
+worst = 0.0
+for s in range(g["nsuper"]):
+    if owner[s] in (rank, -1):
+        a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+        nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+        got, want = f.Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+        low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+        worst = max(worst, float(np.abs(got[low] - want[low]).max() / np.abs(Lo).max()))
+with open(os.path.join({out!r}, f"result_{{rank}}.txt"), "w") as fh:
+    fh.write(f"RESULT {{rank}} {{st}} {{worst}} {{len(run.plan)}}\n")
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_run_with_the_device_kernels(tmp_path):
+    """the N = 2 flow end to end -- subtrees, reduce to the owners, owner-computes top with broadcasts -- with every
+    factor kernel executed from the product's own source on the CPU (emulator key 100 = 3) and gloo as the transport"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_DEVICE_SOURCE.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    import socket
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                             capture_output=True, text=True, env=env, timeout=900)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stdout + out.stderr
+    for r in range(2):
+        l = open(tmp_path / f"result_{r}.txt").read().split()
+        assert int(l[2]) == 0 and float(l[3]) < 1e-10 and int(l[4]) >= 2
