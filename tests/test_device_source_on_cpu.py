@@ -360,3 +360,25 @@ def test_complex_big_tile_kernel_from_source():
     assert (st, minor) == (0, n) and nbig >= 1
     Lg = Lx.reshape(n, n).T
     assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
+
+
+@pytest.mark.parametrize("kind,n,seed,tiny_max", [("arrow", 130, 12, 4096), ("banded", 400, 3, 0), ("arrow", 350, 5, 0)])
+def test_random_structures_through_the_device_kernels(emu, kind, n, seed, tiny_max):  # noqa: F811
+    """the structures of tests/test_fuzz_schedule.py (random graphs, chains, arrowheads: ragged supernodes, scattered
+    relative maps, a 350-column front through k_gemm128) with every factor kernel from its own source"""
+    from oracle import port
+    import test_fuzz_schedule as tf
+    g, rng = tf.build(kind, n, seed)
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    emu.emu_set_tuning(100, 3); emu.emu_set_tuning(14, tiny_max)
+    try:
+        st, minor, Lx, D = run_emu(emu, g)
+    finally:
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+    assert (st, minor) == (so, mo) == (0, n)
+    for s in range(g["nsuper"]):
+        a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+        nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+        got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+        low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+        assert np.abs(got[low] - want[low]).max() <= 1e-10 * np.abs(Lo).max(), s
