@@ -328,7 +328,9 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
             pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
             pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
-            pt.urow0 = (int32_t)(j + nb); pt.pad = 0;
+            pt.urow0 = (int32_t)(j + nb);
+            // a whole supernode of <= 16 columns: one wave factorizes the block AND solves the rows below it
+            pt.fuse_trsm = (tuning().tiny_max > 0 && !S.cplx && ncol_eff <= 16 && below > 0) ? 1 : 0;
             const bool own = !dist || owner(s, j / WB) == dist->rank;
             L[lev].potrf[it].push_back(pt);
             L[lev].mine[it].push_back(own ? 1 : 0);
@@ -461,7 +463,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 pt.dinv_off = out.dinv_size;
                 if (has_below) {
                     ls.trsm[it][ti].b_off = pt.dinv_off;
-                    if (own) trs.push_back(ls.trsm[it][ti]);
+                    if (own && !pt.fuse_trsm) trs.push_back(ls.trsm[it][ti]);
                     ti++;
                 }
                 out.dinv_size += (int64_t)pt.nb * pt.nb;
@@ -634,6 +636,11 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         if (t.dinv_off >= 0 && t.dinv_off + (int64_t)t.nb * t.nb > ds) return bad("potrf task Dinv", (int64_t)i);
         if (t.s < 0 || t.s >= S.nsuper || t.ls_off < 0 || t.ls_off + t.lda > ssz) return bad("potrf task rows", (int64_t)i);
         if (t.urow0 < 0 || t.urow0 > t.lda || (int64_t)t.k1 + t.col0 + t.nb > S.n) return bad("potrf task columns", (int64_t)i);
+        if (t.fuse_trsm) {
+            // k_potrf16 then also writes the rows below the block: the whole panel must lie inside Lx
+            if (t.nb > 16 || t.col0 != 0 || S.cplx || sc.potrf_order.empty()) return bad("fused potrf task shape", (int64_t)i);
+            if (last(t.a_off, t.lda, t.nb, t.lda) >= xs) return bad("fused potrf task panel", (int64_t)i);
+        }
     }
     for (size_t i = 0; i < sc.steps.size(); i++) {
         const Step &st = sc.steps[i];

@@ -58,7 +58,8 @@ struct PotrfTask {
     int32_t k1;         // Super[s]
     int32_t nscol;      // columns of s
     int32_t urow0;      // first row (inside s) of the solve row tiles: col0 + nb, or the end of the solve group
-    int32_t pad;
+    int32_t fuse_trsm;  // != 0 (tiny classes on, a real supernode of <= 16 columns): k_potrf16 also solves the rows below
+                        // the block (the TRSM of the panel step), and the step's TRSM launch has no task for it
 };
 
 // Solve groups (real factor, few right-hand sides): SOLVE_GROUP consecutive 64-column blocks of a supernode are

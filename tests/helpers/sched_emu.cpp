@@ -154,6 +154,15 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                     }
                     for (int i = 0; i < nb; i++) D[i + c * nb] = (i >= c) ? x[i] : 0.0;
                 }
+                if (t.fuse_trsm) {
+                    // the step's TRSM launch has no task for this block: X = B * inv(L11)^T for the rows below
+                    for (int64_t r = nb; r < lda; r++) {
+                        std::vector<double> xr(nb, 0.0);
+                        for (int c = 0; c < nb; c++)
+                            for (int k = 0; k <= c; k++) xr[c] += A[r + k * lda] * D[c + k * nb];
+                        for (int c = 0; c < nb; c++) A[r + c * lda] = xr[c];
+                    }
+                }
             }
         } else if (hostrun::use_device_source >= 3 && !(st.flags & STEP_TINY)) {
             // exactly the engine's GEMM launches of a real factor

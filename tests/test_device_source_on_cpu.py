@@ -35,11 +35,12 @@ def test_factorization_through_the_device_source(emu, name, tiny_max):  # noqa: 
         assert np.array_equal(Lx == 0, g["Lx"] == 0)
 
 
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "lap3d_8_npd200", "tcov_r5lo", "lap2d_16_metis"])
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "tcov_r5lo", "lap2d_16_metis"])
 def test_wave_potrf_source_one_host_thread_per_lane(emu, name):  # noqa: F811
     """k_potrf16 (one wave per diagonal block of <= 16 columns, registers + v_readlane only) from its own source with
-    one host thread per lane: factor, block inverse (the TRSM operand of the steps that follow) and the first bad
-    pivot of the not-positive-definite fixtures.  Slow (a readlane is two 64-thread barriers), hence few fixtures."""
+    one host thread per lane: factor, block inverse, the fused TRSM of the rows below a supernode of <= 16 columns
+    (PotrfTask::fuse_trsm) and the first bad pivot of the not-positive-definite fixture.  Slow (a readlane is two
+    64-thread barriers), hence few fixtures."""
     g = load_golden(name)
     emu.emu_set_tuning(100, 2); emu.emu_set_tuning(14, 4096)
     try:
