@@ -781,7 +781,8 @@ int emu_device_solve(int lower, int mma, int group, int64_t n, int64_t nsuper, c
 // launch sequence (run_schedule) and its not-positive-definite protocol (mi355_factor_numeric).  Ax, Lx: E = 2.
 int emu_device_numeric_c(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
                          const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,
-                         const double *Ax, double beta, int quick, double *Lx, int64_t *minor, int *status, int64_t *nbig)
+                         const double *Ax, double beta, int quick, double *Lx, int64_t *minor, int *status, int64_t *nbig,
+                         double *Dinv_out /* 2 * emu_dinv_size doubles, or NULL */)
 {
     Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
     S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls; S.cplx = true;
@@ -843,6 +844,101 @@ int emu_device_numeric_c(int64_t n, int64_t nsuper, const int64_t *Super, const 
         std::fill(Lx + 2 * tail, Lx + 2 * xsize, 0.0);
     }
     if (nbig) *nbig = big_launches;
+    if (Dinv_out && sf < 0) std::copy(Dinv.begin(), Dinv.begin() + 2 * sc.dinv_size, Dinv_out);
+    return 0;
+}
+
+// The sweeps of a COMPLEX factor with the product's complex solve kernels from their own source, in solve_dev's launch
+// order: mma = 0: k_solve_diag_c + k_solve_fwd_update_c / k_solve_bwd_update_c per block; mma != 0: the MFMA sweeps
+// on the real / imaginary row-major image (k_solve_transpose<double2>, k_solve_group_mma<.., 2, ..> + k_solve_fwd_mma<2> /
+// k_solve_bwd_mma_run<2> when group != 0, else k_solve_diag_mma<.., 2> + k_solve_fwd_mma<2> / k_solve_bwd_mma<2>).
+// X: n x nrhs complex entries (interleaved), column-major, leading dimension d entries.
+int emu_device_solve_c(int lower, int mma, int group, int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi,
+                       const int64_t *Lpx, const int64_t *Ls, int64_t ssize, int64_t xsize, const double *Lx,
+                       const double *Dinv, int64_t nrhs, double *X, int64_t d)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls; S.cplx = true;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    SolveSchedule ss; build_solve_groups(sc, ss);
+    if (!check_schedule_bounds(S, sc, &ss).empty()) return -40;
+    if (n == 0 || nrhs == 0) return 0;
+    std::vector<int32_t> ls32((size_t)Lpi[nsuper] + 1);
+    for (int64_t i = 0; i < Lpi[nsuper]; i++) ls32[i] = (int32_t)Ls[i];
+    const int nr = (int)nrhs, nrr = 2 * nr;
+    const PotrfTask *P = sc.potrf.data();
+    const int32_t *dLs = ls32.data();
+    double *const Xcol = X; const int64_t dcol = d;
+    std::vector<double> yrow;
+    if (mma) {
+        const int64_t ldr = ((int64_t)nrr + 15) & ~(int64_t)15;
+        yrow.assign((size_t)n * (size_t)ldr, 0.0);
+        hipcpu::launch((n + 63) / 64, 256, [&] { k_solve_transpose<double2>(n, nr, reinterpret_cast<double2 *>(Xcol), dcol,
+                                                                            reinterpret_cast<double2 *>(yrow.data()), ldr / 2, 1); });
+        X = yrow.data(); d = ldr;
+    }
+    if (mma && group) {
+        for (size_t ii = 0; ii < ss.steps.size(); ii++) {
+            const SolveStep &st = ss.steps[lower ? ii : ss.steps.size() - 1 - ii];
+            if (st.gcount <= 0) continue;
+            const SolveGroupTask *gp = ss.groups.data() + st.gfirst;
+            const unsigned gy = (unsigned)((nrr + SG_CW - 1) / SG_CW);
+            auto group_kernel = [&]() {
+#define EMU_SGM(T, MB) hipcpu::launch(st.gcount, 256, [&] { k_solve_group_mma<T, 2, MB>(gp, Dinv, Lx, X, d, nrr); }, gy)
+#define EMU_SGM_MB(T) do { if (st.maxblk <= 1) EMU_SGM(T, 1); else if (st.maxblk <= 2) EMU_SGM(T, 2); else EMU_SGM(T, SOLVE_GROUP); } while (0)
+                if (lower) EMU_SGM_MB(false); else EMU_SGM_MB(true);
+#undef EMU_SGM_MB
+#undef EMU_SGM
+            };
+            const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_fwd_div_mma)));
+            const int64_t grid = (st.stiles + grp - 1) / grp;
+            if (lower) {
+                group_kernel();
+                if (st.stiles > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch(grid, 256, [&] { k_solve_fwd_mma<2>(ss.utasks.data() + st.ufirst, ss.tile_task.data() + st.tmap_off, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+            } else {
+                if (st.rmcount > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch(st.rmcount, 256, [&] { k_solve_bwd_mma_run<2>(ss.utasks.data() + st.ufirst, ss.ranges_mma.data() + st.rmfirst, Lx, dLs, X, d, nrr, j0); });
+                group_kernel();
+            }
+        }
+    } else if (lower) {
+        for (const Step &st : sc.steps) {
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            if (mma) hipcpu::launch(st.count, 256, [&] { k_solve_diag_mma<false, 2>(P + st.first, Dinv, X, d, nrr); });
+            else hipcpu::launch(st.count, 256, [&] { k_solve_diag_c<false>(P + st.first, Dinv, X, d, nr); });
+            if (st.stiles > 0) {
+                const int32_t *tm = sc.solve_tile_task.data() + st.tmap_off;
+                if (mma) {
+                    const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch((st.stiles + grp - 1) / grp, 256, [&] { k_solve_fwd_mma<2>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+                } else
+                    hipcpu::launch(st.stiles, SOLVE_ROWS, [&] { k_solve_fwd_update_c(P + st.first, tm, Lx, dLs, X, d, nr); });
+            }
+        }
+    } else {
+        for (size_t i = sc.steps.size(); i-- > 0;) {
+            const Step &st = sc.steps[i];
+            if (st.kind != STEP_POTRF || st.count <= 0) continue;
+            if (st.stiles > 0) {
+                const int32_t *tm = sc.solve_tile_task.data() + st.tmap_off;
+                if (mma) {
+                    const int grp = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / 1024));
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipcpu::launch((st.stiles + grp - 1) / grp, 256, [&] { k_solve_bwd_mma<2>(P + st.first, tm, st.stiles, grp, Lx, dLs, X, d, nrr, j0); });
+                } else
+                    hipcpu::launch(st.stiles, 256, [&] { k_solve_bwd_update_c(P + st.first, tm, Lx, dLs, X, d, nr); });
+            }
+            if (mma) hipcpu::launch(st.count, 256, [&] { k_solve_diag_mma<true, 2>(P + st.first, Dinv, X, d, nrr); });
+            else hipcpu::launch(st.count, 256, [&] { k_solve_diag_c<true>(P + st.first, Dinv, X, d, nr); });
+        }
+    }
+    if (mma)
+        hipcpu::launch((n + 63) / 64, 256, [&] { k_solve_transpose<double2>(n, nr, reinterpret_cast<double2 *>(Xcol), dcol,
+                                                                            reinterpret_cast<double2 *>(yrow.data()), d / 2, 0); });
     return 0;
 }
 #endif

@@ -314,18 +314,25 @@ def test_solve_kernels_from_source_wide_supernode(emu, mma, group, nrhs):  # noq
 # k_gemm64c and k_gemm128<true> (big tasks through the real view).  Needs the emulator built with clang++ (the
 # complex kernels use its vector swizzles); build() does that where /opt/rocm's clang++ exists.
 
-def device_numeric_c(g, quick=0):
+def device_numeric_c(g, quick=0, want_dinv=False):
     lib = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
     if not hasattr(lib, "emu_device_numeric_c"):
         pytest.skip("emulator built without clang++")
     lib.emu_device_numeric_c.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p, i64p,
-                                         f64p, C.c_double, C.c_int, f64p, i64p, C.POINTER(C.c_int), i64p]
+                                         f64p, C.c_double, C.c_int, f64p, i64p, C.POINTER(C.c_int), i64p, C.c_void_p]
+    lib.emu_dinv_size.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64]
+    lib.emu_dinv_size.restype = C.c_int64
     Lx = np.zeros(2 * g["xsize"])
     minor, st, nbig = np.zeros(1, dtype=np.int64), C.c_int(0), np.zeros(1, dtype=np.int64)
+    D = np.zeros(2 * lib.emu_dinv_size(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"],
+                                       g["xsize"]) + 2) if want_dinv else None
     rc = lib.emu_device_numeric_c(g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"],
                                   g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.complex128).view(np.float64),
-                                  g["beta"], quick, Lx, minor, C.byref(st), nbig)
+                                  g["beta"], quick, Lx, minor, C.byref(st), nbig,
+                                  D.ctypes.data_as(C.c_void_p) if want_dinv else None)
     assert rc == 0
+    if want_dinv:
+        return st.value, int(minor[0]), Lx.view(np.complex128), D
     return st.value, int(minor[0]), Lx.view(np.complex128), int(nbig[0])
 
 
@@ -383,3 +390,35 @@ def test_random_structures_through_the_device_kernels(emu, kind, n, seed, tiny_m
         got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
         low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
         assert np.abs(got[low] - want[low]).max() <= 1e-10 * np.abs(Lo).max(), s
+
+
+_CFACTOR = {}
+
+
+@pytest.mark.parametrize("mma,group,nrhs", [(0, 0, 1), (0, 0, 3), (1, 1, 4), (1, 0, 3), (1, 1, 40)])
+@pytest.mark.parametrize("name", ["demo_c", "tcov_c30up", "tcov_z30lo"])
+def test_complex_solve_kernels_from_source(name, mma, group, nrhs):
+    """the complex sweeps: k_solve_diag_c / k_solve_fwd_update_c / k_solve_bwd_update_c per block, and the MFMA sweeps of
+    a complex factor on the real / imaginary row-major image (E = 2 instantiations, k_solve_transpose<double2>), on the
+    factor and the block inverses the complex factor kernels produced -- everything from the product's own source"""
+    from oracle import port
+    g = load_golden(name)
+    if name not in _CFACTOR:
+        _CFACTOR[name] = device_numeric_c(g, want_dinv=True)
+    st, minor, Lx, D = _CFACTOR[name]
+    assert st == 0
+    lib = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
+    lib.emu_device_solve_c.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64,
+                                       C.c_int64, f64p, f64p, C.c_int64, f64p, C.c_int64]
+    a = [g["n"], g["nsuper"], g["Super"], g["Lpi"], g["Lpx"], g["Ls"], g["ssize"], g["xsize"]]
+    n = g["n"]
+    rng = np.random.default_rng(nrhs)
+    B = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+    Yo = port.super_solve(g, g["Lx"], B, lower=True)
+    Xo = port.super_solve(g, g["Lx"], Yo, lower=False)
+    X = np.ascontiguousarray(B.T).reshape(-1).copy().view(np.float64)
+    Lxf = np.ascontiguousarray(Lx).view(np.float64)
+    assert lib.emu_device_solve_c(1, mma, group, *a, Lxf, D, nrhs, X, n) == 0
+    assert relerr(X.view(np.complex128).reshape(nrhs, n).T, Yo) < 1e-9
+    assert lib.emu_device_solve_c(0, mma, group, *a, Lxf, D, nrhs, X, n) == 0
+    assert relerr(X.view(np.complex128).reshape(nrhs, n).T, Xo) < 1e-9
