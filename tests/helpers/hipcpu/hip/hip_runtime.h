@@ -4,7 +4,10 @@
 // wave, blockDim.x / 64 waves per workgroup.  Only what those kernels use exists here:
 //   threadIdx / blockIdx / blockDim, __shared__ (a function-local static: workgroups run one after the other),
 //   __syncthreads (a barrier over the workgroup's threads), v_readlane / readfirstlane / __shfl / __shfl_xor and
-//   v_mfma_f64_16x16x4_f64 (an exchange through per-wave arrays between two wave barriers), FP64 atomic add.
+//   v_mfma_f64_16x16x4_f64 (an exchange through per-wave arrays between two wave barriers), FP64 atomic add;
+//   and the slice of the HIP runtime API the engine's host code calls (device memory = host memory, streams and
+//   events = nothing, hipLaunchKernelGGL = hipcpu::launch), so that engine.hip itself builds as a CPU library with the
+//   same C ABI (tests/helpers/libmi355_cpuemu.so, loaded by tests only).
 // MFMA operand and result layout as the kernels assume it and the GPU runs confirmed it: lane l supplies
 // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; lane l, register r holds D[i = (l >> 4) + 4 r][j = l & 15].
 // Never part of the product; the emulator (tests/helpers/sched_emu.cpp) is its only user.
@@ -20,10 +23,10 @@ namespace hipcpu {
 struct Dim { unsigned x = 1, y = 1, z = 1; };
 struct Wave { pthread_barrier_t bar; int64_t slot[64]; double a[64], b[64]; };
 struct Block { pthread_barrier_t bar; Wave wave[16]; };
-extern thread_local Dim threadIdx, blockIdx, blockDim, gridDim;
-extern thread_local Block *blk;         // null: the thread-by-thread mode (kernels without any cross-lane operation)
-extern thread_local Wave *wav;
-extern thread_local int lane;
+inline thread_local Dim threadIdx, blockIdx, blockDim, gridDim;
+inline thread_local Block *blk = nullptr;   // null: the thread-by-thread mode (kernels without any cross-lane operation)
+inline thread_local Wave *wav = nullptr;
+inline thread_local int lane = 0;
 
 inline void syncthreads() { pthread_barrier_wait(&blk->bar); }
 inline int64_t exchange(int64_t v, int src)
@@ -147,9 +150,60 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ULL)
+#define __builtin_amdgcn_s_memrealtime() (0ULL)
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipcpu::mfma_f64_16x16x4((a), (b), (c))
 #define __shfl(...) hipcpu::shfl(__VA_ARGS__)
 #define __shfl_xor(...) hipcpu::shfl_xor(__VA_ARGS__)
 #define __double2loint(d) hipcpu::d2lo(d)
 #define __double2hiint(d) hipcpu::d2hi(d)
 #define __hiloint2double(hi, lo) hipcpu::hilo2d((hi), (lo))
+
+// ---- the HIP runtime API the engine's host code uses; everything is synchronous
+#include <chrono>
+#include <cstdlib>
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+typedef void *hipStream_t;
+struct hipcpuEvent { std::chrono::steady_clock::time_point t; };
+typedef hipcpuEvent *hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount = 1; };
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "hipcpu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::strcpy(p->gcnArchName, "gfx950:cpu-emulation"); return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (void *)1; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipcpuEvent; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{ *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t)
+{ for (size_t r = 0; r < h; r++) std::memcpy((char *)d + r * dp, (const char *)s + r * sp, w); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+namespace hipcpu {
+template <class F> void launch_dims(dim3 g, dim3 b, F call)
+{
+    // blocks of any width: pad to whole waves (the extra lanes must not exist for the kernel, so only multiples of 64
+    // are accepted -- every kernel of the product is launched with 64 or 256 threads)
+    if (b.x % 64 != 0 || b.y != 1 || b.z != 1 || g.z != 1) std::abort();
+    if (g.x == 0 || g.y == 0) return;
+    launch((int64_t)g.x, b.x, call, g.y);
+}
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipcpu::launch_dims(dim3(grid), dim3(block), [&] { (kernel)(__VA_ARGS__); })

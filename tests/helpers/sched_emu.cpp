@@ -16,7 +16,6 @@ using namespace mi355;
 // without cross-lane operations run thread after thread (launch_serial), the others with one host thread per
 // lane (launch).  Emulator key 100: 1 = assembly, k_relmap, k_gemm_tiny; 2 = also k_potrf16; 3 = every kernel of
 // the real factorization (k_potrf64, k_trsm64, k_gemm64, k_gemm128) with the engine's launch geometry.
-namespace hipcpu { thread_local Dim threadIdx, blockIdx, blockDim, gridDim; thread_local Block *blk = nullptr; thread_local Wave *wav = nullptr; thread_local int lane = 0; }
 #include "../../suitesparse_amd/csrc/kernels.hip.hpp"
 #include "../../suitesparse_amd/csrc/solve_kernels.hip.hpp"
 #ifdef __clang__

@@ -1,0 +1,150 @@
+"""The GPU test bodies, on the CPU.  build() compiles the engine ITSELF -- engine.hip's host code and every kernel, the
+whole C ABI of include/mi355_cholmod.h -- for the host against tests/helpers/hipcpu/hip/hip_runtime.h (device memory =
+host memory, a launch = one host thread per lane) into tests/helpers/libmi355_cpuemu.so.  Here the Python binding is
+pointed at that library (from the test only: the product knows nothing of it and has no CPU path) and the bodies of
+the GPU tests run on small cases.  What this covers that the schedule emulator cannot: the engine's host logic --
+staging and validation, the launch sequences of run_schedule and solve_dev, the not-positive-definite protocol, the
+permutations of mi355_solve, rcond, the simplicial conversion -- together with the kernels, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, sym_of, relerr
+
+CPUEMU = os.path.join(ROOT, "tests", "helpers", "libmi355_cpuemu.so")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    if not os.path.exists(CPUEMU):
+        pytest.skip("libmi355_cpuemu.so not built (needs /opt/rocm's clang++)")
+    from suitesparse_amd import engine as e
+    saved = (e.LIB_PATH, e._LIB)
+    e.LIB_PATH, e._LIB = CPUEMU, None
+    try:
+        assert e.probe() == 1
+        yield e
+    finally:
+        e.LIB_PATH, e._LIB = saved
+
+
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_c30lo_singular", "tcov_r5lo",
+                                  "tcov_z5up", "lap2d_16_npd0", "tcov_ex5lo"])
+def test_golden_factor_and_solve(engine, name):
+    import test_gpu_parity as t
+    t.test_golden_factor_and_solve(engine, name)
+
+
+def test_quick_return_if_not_posdef(engine):
+    import test_gpu_parity as t
+    t.test_quick_return_if_not_posdef(engine, "lap2d_16_npd0")
+
+
+def test_error_paths_and_empty_factor(engine):
+    import test_gpu_parity as t
+    t.test_error_paths(engine)
+    t.test_empty_factor(engine)
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 130])
+def test_dense_single_supernode(engine, n):
+    import test_gpu_parity as t
+    t.test_dense_single_supernode(engine, n)
+
+
+def test_zomplex_input_gives_complex_factor(engine):
+    import test_gpu_parity as t
+    t.test_zomplex_input_gives_complex_factor(engine)
+
+
+def test_solve2_with_permutation_all_systems(engine):
+    """mi355_solve (cholmod_solve2's supernodal branch): Y = P b, sweeps, x = P' y on the 'device', every sys value,
+    against dense algebra on the golden factor; real L with a complex right-hand side (the dual path)"""
+    g = load_golden("demo_bcsstk01")
+    n = g["n"]
+    L = engine.SupernodalFactor(sym_of(g))
+    assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == 0
+    L.set_perm(g["Perm"])
+    import test_unsym as tu
+    Ld = tu.dense_L(g, g["Lx"])
+    P = np.zeros((n, n))
+    P[np.arange(n), g["Perm"]] = 1.0                         # (P b)[k] = b[Perm[k]]
+    rng = np.random.default_rng(0)
+    for B in (rng.standard_normal((n, 2)), rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))):
+        want = {0: P.T @ np.linalg.solve(Ld @ Ld.T, P @ B), 1: np.linalg.solve(Ld @ Ld.T, B),
+                2: np.linalg.solve(Ld, B), 3: np.linalg.solve(Ld.T, B), 4: np.linalg.solve(Ld, B),
+                5: np.linalg.solve(Ld.T, B), 6: B, 7: P @ B, 8: P.T @ B}
+        for sys_, w in want.items():
+            assert relerr(L.solve(B, sys=sys_), w) < 1e-9, sys_
+    L.close()
+
+
+def test_device_side_permutation_rcond_and_simplicial(engine):
+    """mi355_factor_set_matrix_perm (A + Perm instead of S), mi355_factor_rcond, mi355_factor_to_simplicial"""
+    import scipy.sparse as sp
+    g = load_golden("lap3d_8_amd") if False else load_golden("demo_bcsstk01")
+    n = g["n"]
+    A = sp.csc_matrix((g["Ax"], g["Ai"], g["Ap"]), shape=(n, n))
+    if g["stype"] > 0:
+        A = A.T.tocsc()
+    A = sp.tril(A, format="csc")
+    A.sort_indices()
+    L = engine.SupernodalFactor(sym_of(g))
+    L.set_matrix_perm(A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data, g["Perm"])
+    assert L.numeric() == 0
+    assert relerr(L.Lx(), g["Lx"]) < 1e-10
+    import test_unsym as tu
+    Ld = tu.dense_L(g, g["Lx"])
+    d = np.diag(Ld)
+    assert abs(L.rcond() - (d.min() / d.max()) ** 2) < 1e-12
+    Lp, Li, Lnz, Lv = L.to_simplicial(True)
+    got = sp.csc_matrix((Lv, Li, Lp), shape=(n, n)).toarray()
+    assert relerr(got, Ld) < 1e-10
+    Lp, Li, Lnz, Lv = L.to_simplicial(False)                 # LDL': D on the diagonal, unit-scaled columns
+    got = sp.csc_matrix((Lv, Li, Lp), shape=(n, n)).toarray()
+    assert relerr(np.diag(got), d ** 2) < 1e-10
+    assert relerr(np.tril(got, -1), np.tril(Ld / d[None, :], -1)) < 1e-10
+    L.close()
+
+
+# ---- this session's additions, which no GPU has run yet
+
+def test_unsym_through_the_abi(engine):
+    """mi355_factor_set_matrix_unsym + k_assemble_aat: every unsymmetric fixture (real, complex, beta), zomplex and
+    unpacked inputs, the argument checks"""
+    import test_unsym as tu
+    for name in tu.unsym_names():
+        tu.test_gpu_golden_unsym(engine, name)
+    tu.test_gpu_unsym_zomplex_unpacked_and_errors(engine)
+
+
+@pytest.mark.parametrize("case", [0, 2, 4])
+def test_unsym_live_through_the_abi(engine, have_ref, case):
+    import test_unsym as tu
+    tu.test_gpu_live_unsym(engine, have_ref, *tu.LIVE[case])
+
+
+def test_unsym_fset_through_the_abi(engine, have_ref):
+    import test_unsym as tu
+    tu.test_gpu_column_subset_fset(engine, have_ref, *tu.FSET[0])
+
+
+@pytest.mark.parametrize("name,tiny_max", [("demo_bcsstk01", 4096), ("lap2d_16_metis", 4096), ("lap2d_16_npd0", 1 << 18),
+                                           ("tcov_ex5lo", 64), ("demo_bcsstk02", 4096)])
+def test_tiny_launch_classes_through_the_abi(engine, name, tiny_max):
+    """tuning key 14 through the engine: the potrf order list upload, k_potrf16 (+ fused TRSM) / k_potrf64 with the order,
+    k_gemm_tiny launches"""
+    import wip_tiny_tasks as w
+    w.test_tiny_launch_class_golden(engine, name, tiny_max)
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 80])
+def test_small_dense_supernode_through_the_wave_potrf(engine, n):
+    import wip_tiny_tasks as w
+    w.test_small_dense_supernode_through_the_wave_potrf(engine, n)
+
+
+def test_wave_potrf_reports_the_first_bad_pivot(engine):
+    import wip_tiny_tasks as w
+    w.test_wave_potrf_reports_the_first_bad_pivot(engine)
