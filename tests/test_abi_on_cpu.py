@@ -148,3 +148,130 @@ def test_small_dense_supernode_through_the_wave_potrf(engine, n):
 def test_wave_potrf_reports_the_first_bad_pivot(engine):
     import wip_tiny_tasks as w
     w.test_wave_potrf_reports_the_first_bad_pivot(engine)
+
+
+# ---- the multi-GPU entry points of the C ABI (set_partition, numeric_phase, set_top_distribution, top_plan, top_run,
+# solve_phase_dev, keep_rows_dev) with several handles in one process; "device" memory is host memory here, so the
+# views RCCL would work on are numpy / torch views of the same buffers
+
+class EngineFactor:
+    """the interface multigpu.PartitionedFactor expects, on a real engine handle of the CPU build"""
+
+    def __init__(self, engine, g):
+        import ctypes as C
+        self.e, self.g = engine, g
+        self.L = engine.SupernodalFactor(g)
+        self.L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        self.Lx = np.ctypeslib.as_array((C.c_double * int(g["xsize"])).from_address(self.L.device_Lx_ptr()))
+        nd = int(self.L.stats()["dinv_entries"])
+        self.Dinv = np.ctypeslib.as_array((C.c_double * max(nd, 1)).from_address(
+            engine.lib().mi355_factor_device_Dinv(self.L._h)))
+        self.minor = g["n"]
+
+    def set_partition(self, *m): self.L.set_partition(*m)
+    def numeric_phase(self, phase, beta=0.0): return self.L.numeric_phase(phase, beta)
+    def set_top_distribution(self, rank, world): return self.L.set_top_distribution(rank, world)
+    def top_run(self, seg): return self.L.top_run(seg)
+    def solve_phase_dev(self, part, lower, X_ptr, nrhs, d): self.L.solve_phase_dev(part, lower, X_ptr, nrhs, d)
+    def keep_rows_dev(self, X_ptr, nrhs, d): self.L.keep_rows_dev(X_ptr, nrhs, d)
+
+    def numeric(self, beta=0.0, quick=False):
+        st = self.L.numeric(beta, quick)
+        self.minor = self.L.minor
+        return st
+
+    def top_tensors(self, ranges):
+        import torch
+        t = torch.from_numpy(self.Lx)
+        return [t[lo:hi] for lo, hi in ranges]
+
+    def dinv_tensors(self, ranges):
+        import torch
+        t = torch.from_numpy(self.Dinv)
+        return [t[lo:hi] for lo, hi in ranges]
+
+
+@pytest.mark.parametrize("world,spoil", [(3, False), (2, True)])
+def test_partitioned_factor_through_the_abi(engine, world, spoil):
+    """N handles = N simulated ranks: subtrees, reduce to the owners (partial sums left elsewhere, as after a real
+    reduce), owner-computes top segment by segment with the broadcasts done by hand, block inverses summed, the solves on
+    the partitioned factor; spoil: a negative pivot, every rank must end with the reference's minor and factor"""
+    import torch
+    from oracle import port
+    from suitesparse_amd import multigpu
+    from test_multigpu import problem
+    g = dict(problem("lap3d", 7))
+    n = g["n"]
+    if spoil:
+        Sx = g["Sx"].copy()
+        Sx[g["Sp"][n // 2]] = -3.0
+        g["Sx"] = Sx
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    engine.set_tuning(2, 64); engine.set_tuning(7, 64)            # 64-column outer blocks: the top spreads over the ranks
+    try:
+        facs = [EngineFactor(engine, g) for _ in range(world)]
+        runs = [multigpu.PartitionedFactor(f, g, r, world, distribute_top=True, min_subtrees_per_rank=1,
+                                           reduce=lambda ts, roots: None) for r, f in enumerate(facs)]
+        assert all(rn.dist and rn.reduce is not None for rn in runs)
+        plan = runs[0].plan
+        for rn in runs[1:]:
+            assert (rn.plan[:, 1:] == plan[:, 1:]).all()
+        res0 = [rn.f.numeric_phase(0) for rn in runs]
+        failed = any(b >= 0 for b, _ in res0)
+        if not failed:
+            for k, (step, lo, cnt, root) in enumerate(plan):
+                tot = sum(rn.bviews[k].clone() for rn in runs)
+                runs[int(root)].bviews[k][...] = tot
+            for k in range(len(plan)):
+                for rn in runs:
+                    rn.f.top_run(k)
+                root = int(plan[k, 3])
+                for rn in runs:
+                    if rn.rank != root:
+                        rn.bviews[k][...] = runs[root].bviews[k]
+            res1 = [rn.f.top_run(len(plan)) for rn in runs]
+            failed = any(b >= 0 for b, _ in res1)
+        assert failed == spoil
+        if spoil:
+            for rn in runs:
+                st = rn._replay(0.0, False)
+                assert (st, rn.minor) == (so, mo) == (1, mo)
+                assert relerr(rn.f.Lx, Lo) < 1e-10 and np.array_equal(rn.f.Lx == 0, Lo == 0)
+            return
+        if runs[0].dinv_views:
+            tot = sum(rn.dinv_views[0].clone() for rn in runs)
+            for rn in runs:
+                rn.dinv_views[0][...] = tot
+        owner = runs[0].part["owner"]
+        for r, f in enumerate(facs):
+            for s in range(g["nsuper"]):
+                if owner[s] in (r, -1):
+                    a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                    nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                    got, want = f.Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                    low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+                    assert relerr(got[low], want[low]) < 1e-10, (r, s)
+        for rn in runs:                      # the engine only solves on a factor it saw complete
+            rn.status = 0
+        B = np.random.default_rng(1).standard_normal((2, n))
+        want = port.super_solve(g, Lo, port.super_solve(g, Lo, B.T.copy(), lower=True), lower=False).T
+        Xs = [torch.from_numpy(B.copy()) for _ in range(world)]
+
+        def summed():
+            tot = sum(x.numpy().copy() for x in Xs)
+            for x in Xs:
+                x.numpy()[...] = tot
+        for rn, x in zip(runs, Xs):
+            rn.f.keep_rows_dev(x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(0, True, x.data_ptr(), 2, n)
+        summed()
+        for rn, x in zip(runs, Xs):
+            rn.f.solve_phase_dev(1, True, x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(1, False, x.data_ptr(), 2, n)
+            rn.f.solve_phase_dev(0, False, x.data_ptr(), 2, n)
+            rn.f.keep_rows_dev(x.data_ptr(), 2, n)
+        summed()
+        for x in Xs:
+            assert relerr(x.numpy(), want) < 1e-9
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
