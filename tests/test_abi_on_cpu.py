@@ -19,14 +19,16 @@ CPUEMU = os.path.join(ROOT, "tests", "helpers", "libmi355_cpuemu.so")
 def engine():
     if not os.path.exists(CPUEMU):
         pytest.skip("libmi355_cpuemu.so not built (needs /opt/rocm's clang++)")
-    from suitesparse_amd import engine as e
+    from suitesparse_amd import engine as e, symbolic
     saved = (e.LIB_PATH, e._LIB)
     e.LIB_PATH, e._LIB = CPUEMU, None
+    symbolic._ready = False              # its argtypes are set once per library object
     try:
         assert e.probe() == 1
         yield e
     finally:
         e.LIB_PATH, e._LIB = saved
+        symbolic._ready = False
 
 
 @pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_c30lo_singular", "tcov_r5lo",
