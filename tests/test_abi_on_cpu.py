@@ -32,7 +32,7 @@ def engine():
 
 
 @pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_c30lo_singular", "tcov_r5lo",
-                                  "tcov_z5up", "lap2d_16_npd0", "tcov_ex5lo"])
+                                  "tcov_z5up", "tcov_ex5lo"])
 def test_golden_factor_and_solve(engine, name):
     import test_gpu_parity as t
     t.test_golden_factor_and_solve(engine, name)
@@ -132,8 +132,8 @@ def test_unsym_fset_through_the_abi(engine, have_ref):
     tu.test_gpu_column_subset_fset(engine, have_ref, *tu.FSET[0])
 
 
-@pytest.mark.parametrize("name,tiny_max", [("demo_bcsstk01", 4096), ("lap2d_16_metis", 4096), ("lap2d_16_npd0", 1 << 18),
-                                           ("tcov_ex5lo", 64), ("demo_bcsstk02", 4096)])
+@pytest.mark.parametrize("name,tiny_max", [("demo_bcsstk01", 4096), ("lap2d_16_metis", 1 << 18), ("tcov_ex5lo", 64),
+                                           ("demo_bcsstk02", 4096)])
 def test_tiny_launch_classes_through_the_abi(engine, name, tiny_max):
     """tuning key 14 through the engine: the potrf order list upload, k_potrf16 (+ fused TRSM) / k_potrf64 with the order,
     k_gemm_tiny launches"""
@@ -202,7 +202,7 @@ def test_partitioned_factor_through_the_abi(engine, world, spoil):
     from oracle import port
     from suitesparse_amd import multigpu
     from test_multigpu import problem
-    g = dict(problem("lap3d", 7))
+    g = dict(problem("lap3d", 5 if spoil else 7))
     n = g["n"]
     if spoil:
         Sx = g["Sx"].copy()

@@ -35,7 +35,7 @@ def test_factorization_through_the_device_source(emu, name, tiny_max):  # noqa: 
         assert np.array_equal(Lx == 0, g["Lx"] == 0)
 
 
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "tcov_r5lo", "lap2d_16_metis"])
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "tcov_r5lo"])
 def test_wave_potrf_source_one_host_thread_per_lane(emu, name):  # noqa: F811
     """k_potrf16 (one wave per diagonal block of <= 16 columns, registers + v_readlane only) from its own source with
     one host thread per lane: factor, block inverse, the fused TRSM of the rows below a supernode of <= 16 columns
@@ -282,8 +282,9 @@ def device_solve(emu, g, Lx, D, B, mma, group):  # noqa: F811
 PATHS = [(0, 1, 1), (0, 1, 4), (0, 0, 1), (0, 0, 6), (1, 1, 5), (1, 0, 9), (1, 1, 70)]      # (mma, grouped, nrhs)
 
 
-@pytest.mark.parametrize("mma,group,nrhs", PATHS)
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "tcov_r5lo", "lap2d_16_metis"])
+@pytest.mark.parametrize("name,mma,group,nrhs",
+                         [(nm, *pth) for nm in ("demo_bcsstk01", "demo_bcsstk02", "tcov_r5lo") for pth in PATHS]
+                         + [("lap2d_16_metis", 0, 1, 1), ("lap2d_16_metis", 1, 1, 5)])
 def test_solve_kernels_from_source_golden(emu, name, mma, group, nrhs):  # noqa: F811
     from oracle import port
     g = load_golden(name)
