@@ -50,3 +50,19 @@ def test_product_does_not_link_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("the oracle", ""), f"{f} mentions oracle/"
+
+
+def test_product_knows_nothing_of_the_cpu_emulation():
+    """tests/helpers/hipcpu and libmi355_cpuemu.so are test infrastructure: nothing under suitesparse_amd/, bench.py
+    or __graft_entry__.smoke() may name them (only build() compiles them, and only tests load them)"""
+    import inspect
+    for root, _, files in os.walk(os.path.join(ROOT, "suitesparse_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "cpuemu" not in txt and "hipcpu" not in txt, f
+    assert "cpuemu" not in open(os.path.join(ROOT, "bench.py")).read()
+    import __graft_entry__ as ge
+    assert "cpuemu" not in inspect.getsource(ge.smoke)
+    from suitesparse_amd import engine
+    assert engine.LIB_PATH.endswith(os.path.join("suitesparse_amd", "libmi355_cholmod.so"))
