@@ -351,3 +351,11 @@ def test_two_process_gloo_run_on_the_engine(engine, tmp_path):
         st, worst, st2, minor2, so2, mo2, same = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7]), int(l[8])
         assert st == 0 and worst < 1e-9
         assert st2 == so2 == 1 and minor2 == mo2 and same == 1
+
+
+@pytest.mark.parametrize("kind,size", [("lap3d", 4), ("helm", 3)])
+def test_every_solve_path_through_the_abi(engine, kind, size):
+    """solve_dev's dispatch (tuning keys 9 / 10: scalar or MFMA kernels, grouped or per block; real and complex) through
+    mi355_super_lsolve / _ltsolve, for 1, 3, 7 and 20 right-hand sides"""
+    import test_gpu_parity as t
+    t.test_every_solve_path_against_the_oracle(engine, kind, size)
