@@ -359,3 +359,40 @@ def test_every_solve_path_through_the_abi(engine, kind, size):
     mi355_super_lsolve / _ltsolve, for 1, 3, 7 and 20 right-hand sides"""
     import test_gpu_parity as t
     t.test_every_solve_path_against_the_oracle(engine, kind, size)
+
+
+@pytest.mark.parametrize("kind,n,seed,tiny_max", [("arrow", 150, 32, 0), ("sparse", 60, 35, 2048)])
+def test_random_structure_end_to_end_through_the_abi(engine, kind, n, seed, tiny_max):
+    """random SPD structure under a random permutation, the way a CHOLMOD caller would use the library: our symbolic
+    analysis, A + Perm staged (assembly through the inverse permutation), numeric, mi355_solve with CHOLMOD_A --
+    residual of A x = b in the ORIGINAL ordering, and the factor against the oracle's"""
+    import scipy.sparse as sp
+    import test_fuzz_schedule as tf
+    from oracle import port
+    from suitesparse_amd import symbolic
+    rng = np.random.default_rng(seed)
+    Ap, Ai, Ax = tf.random_spd(kind, n, seed)
+    sym = symbolic.analyze(n, Ap, Ai, rng.permutation(n))
+    Sp, Si, Sx = symbolic.permute(sym, Ap, Ai, Ax)
+    so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx)
+    engine.set_tuning(14, tiny_max)
+    try:
+        L = engine.SupernodalFactor(sym)
+        L.set_matrix_perm(Ap, Ai, Ax, sym["Perm"])
+        assert L.numeric() == so == 0
+        Lx = L.Lx()
+        L.set_perm(sym["Perm"])
+        A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+        A = A + sp.tril(A, -1).T
+        B = rng.standard_normal((n, 3))
+        X = L.solve(B, sys=0)
+        L.close()
+    finally:
+        engine.set_tuning(14, 0)
+    assert np.abs(A @ X - B).max() <= 1e-12 * np.abs(B).max() * n
+    for s in range(sym["nsuper"]):
+        a, b = int(sym["Lpx"][s]), int(sym["Lpx"][s + 1])
+        nsrow = int(sym["Lpi"][s + 1] - sym["Lpi"][s])
+        got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+        low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+        assert np.abs(got[low] - want[low]).max() <= 1e-10 * np.abs(Lo).max()
