@@ -890,29 +890,6 @@ __global__ __launch_bounds__(64 * POTRF16_WAVES) void k_potrf16(
         __builtin_amdgcn_sched_barrier(0);
     }
     if (lane == 0 && fail_col != 0 && info[t.s] == 0) info[t.s] = t.col0 + fail_col;
-    if (t.fuse_trsm) {
-        // the TRSM of the panel step (worker :1175: X = B * inv(L11)^T) for the rows below the block, 64 rows at a
-        // time, lane = row: x[c] = sum_{k <= c} B[row][k] * W[c][k], W[c][k] = w[c] of lane k.  The trip count and
-        // every cross-lane read are wave-uniform; rows beyond the panel are masked at the loads and stores only.
-        const int below = (int)lda - nb;
-        for (int r0 = 0; r0 < below; r0 += 64) {
-            const int row = nb + r0 + lane;
-            const bool ok = row < (int)lda;
-            double b[16], x[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) b[k] = (ok && k < nb) ? A[row + (int64_t)k * lda] : 0.0;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k <= c; k++) acc += b[k] * lane_bcast(w[c], k);
-                x[c] = acc;
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++)
-                if (ok && c < nb) A[row + (int64_t)c * lda] = x[c];
-        }
-    }
     if (lane < nb) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
@@ -922,6 +899,27 @@ __global__ __launch_bounds__(64 * POTRF16_WAVES) void k_potrf16(
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 if (i < nb) D[i] = (i >= lane) ? w[i] : 0.0;
+        }
+    }
+    // (the factor and the inverse are stored first: only w stays live through the solve below)
+    if (t.fuse_trsm) {
+        // the TRSM of the panel step (worker :1175: X = B * inv(L11)^T) for the rows below the block, 64 rows at a
+        // time, lane = row: x[c] = sum_{k <= c} B[row][k] * W[c][k], W[c][k] = w[c] of lane k.  The trip count and
+        // every cross-lane read are wave-uniform; rows beyond the panel are masked at the loads and stores only.
+        const int below = (int)lda - nb;
+        for (int r0 = 0; r0 < below; r0 += 64) {
+            const int row = nb + r0 + lane;
+            const bool ok = row < (int)lda;
+            double b[16];                                     // the whole row first: the results overwrite it
+#pragma unroll
+            for (int k = 0; k < 16; k++) b[k] = (ok && k < nb) ? A[row + (int64_t)k * lda] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k <= c; k++) acc += b[k] * lane_bcast(w[c], k);
+                if (ok && c < nb) A[row + (int64_t)c * lda] = acc;
+            }
         }
     }
 }
