@@ -160,7 +160,7 @@ struct Schedule {
     // With Tuning::tiny_max > 0 and a real factor: per POTRF step (same offsets as potrf[]), the step's task indices
     // (relative to the step) with the blocks of at most 16 columns first -- 98 % of the diagonal blocks of a 2D
     // problem, 85 % of a 3D one: k_potrf64 holds two workgroups per CU (its 64 x 64 LDS images), k_potrf16 keeps such
-    // a block in the registers of one wave and sixteen of them per CU.  The task order itself is left alone (the
+    // a block in the registers of one wave and twelve of them per CU.  The task order itself is left alone (the
     // solve work lists are built over it).  Empty otherwise.
     std::vector<int32_t> potrf_order;
     std::vector<GemmTask> gemm;
