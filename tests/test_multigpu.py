@@ -274,9 +274,10 @@ def test_not_posdef_on_a_partition_replays_the_reference_protocol(where, quick):
         assert ((rn.f.Lx == 0) == (Lo == 0)).all()
 
 
-@pytest.mark.parametrize("kind,size,world,ob2", [("lap3d", 14, 4, 128), ("lap3d", 12, 3, 1024), ("lap2d", 40, 8, 64),
-                                                 ("elast", 5, 2, 64)])
-def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2):
+@pytest.mark.parametrize("kind,size,world,ob2,tiny_max", [("lap3d", 14, 4, 128, 0), ("lap3d", 12, 3, 1024, 0),
+                                                          ("lap2d", 40, 8, 64, 4096), ("elast", 5, 2, 64, 0),
+                                                          ("lap3d", 12, 2, 64, 1 << 16)])
+def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2, tiny_max):
     """the blocks of the broadcast plan tile the top panels exactly, so reducing every block to its owner replaces the
     all-reduce: simulated ranks, the reduction done by hand block by block (non-owners keep their partial sums, as
     after a real reduce), then the distributed top; every rank must end with the oracle's factor"""
@@ -285,6 +286,7 @@ def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2):
     so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
     emu = C.CDLL(os.path.join(ROOT, "tests", "helpers", "libsched_emu.so"))
     emu.emu_set_tuning(2, min(64, ob2)); emu.emu_set_tuning(7, ob2)
+    emu.emu_set_tuning(14, tiny_max)            # the tiny launch classes (order lists, fused TRSM) under a partition too
     try:
         facs = [EmuFactor(g) for _ in range(world)]
         calls = []
@@ -311,7 +313,7 @@ def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2):
                     low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
                     assert relerr(got[low], want[low]) < 1e-11, (r, s)
     finally:
-        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024)
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 0)
 
 
 def run_distributed_lockstep(runners, facs):
