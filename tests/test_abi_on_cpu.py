@@ -193,8 +193,8 @@ class EngineFactor:
         return [t[lo:hi] for lo, hi in ranges]
 
 
-@pytest.mark.parametrize("world,spoil", [(3, False), (2, True)])
-def test_partitioned_factor_through_the_abi(engine, world, spoil):
+@pytest.mark.parametrize("world,spoil,tiny_max", [(3, False, 0), (2, True, 0), (2, False, 4096)])
+def test_partitioned_factor_through_the_abi(engine, world, spoil, tiny_max):
     """N handles = N simulated ranks: subtrees, reduce to the owners (partial sums left elsewhere, as after a real
     reduce), owner-computes top segment by segment with the broadcasts done by hand, block inverses summed, the solves on
     the partitioned factor; spoil: a negative pivot, every rank must end with the reference's minor and factor"""
@@ -210,6 +210,7 @@ def test_partitioned_factor_through_the_abi(engine, world, spoil):
         g["Sx"] = Sx
     so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
     engine.set_tuning(2, 64); engine.set_tuning(7, 64)            # 64-column outer blocks: the top spreads over the ranks
+    engine.set_tuning(14, tiny_max)
     try:
         facs = [EngineFactor(engine, g) for _ in range(world)]
         runs = [multigpu.PartitionedFactor(f, g, r, world, distribute_top=True, min_subtrees_per_rank=1,
@@ -276,7 +277,7 @@ def test_partitioned_factor_through_the_abi(engine, world, spoil):
         for x in Xs:
             assert relerr(x.numpy(), want) < 1e-9
     finally:
-        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(14, 0)
 
 
 WORKER_ENGINE = r'''
