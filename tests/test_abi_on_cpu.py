@@ -132,8 +132,7 @@ def test_unsym_fset_through_the_abi(engine, have_ref):
     tu.test_gpu_column_subset_fset(engine, have_ref, *tu.FSET[0])
 
 
-@pytest.mark.parametrize("name,tiny_max", [("demo_bcsstk01", 4096), ("lap2d_16_metis", 1 << 18), ("tcov_ex5lo", 64),
-                                           ("demo_bcsstk02", 4096)])
+@pytest.mark.parametrize("name,tiny_max", [("demo_bcsstk01", 1 << 18), ("tcov_ex5lo", 64), ("demo_bcsstk02", 4096)])
 def test_tiny_launch_classes_through_the_abi(engine, name, tiny_max):
     """tuning key 14 through the engine: the potrf order list upload, k_potrf16 (+ fused TRSM) / k_potrf64 with the order,
     k_gemm_tiny launches"""

@@ -35,7 +35,7 @@ def test_factorization_through_the_device_source(emu, name, tiny_max):  # noqa: 
         assert np.array_equal(Lx == 0, g["Lx"] == 0)
 
 
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "lap2d_16_npd0", "tcov_r5lo"])
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "tcov_r5lo", "elast27_4_npd100"])
 def test_wave_potrf_source_one_host_thread_per_lane(emu, name):  # noqa: F811
     """k_potrf16 (one wave per diagonal block of <= 16 columns, registers + v_readlane only) from its own source with
     one host thread per lane: factor, block inverse, the fused TRSM of the rows below a supernode of <= 16 columns
@@ -371,7 +371,7 @@ def test_complex_big_tile_kernel_from_source():
     assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < 1e-11
 
 
-@pytest.mark.parametrize("kind,n,seed,tiny_max", [("arrow", 130, 12, 4096), ("banded", 400, 3, 0), ("arrow", 350, 5, 0)])
+@pytest.mark.parametrize("kind,n,seed,tiny_max", [("arrow", 130, 12, 4096), ("banded", 400, 3, 0)])
 def test_random_structures_through_the_device_kernels(emu, kind, n, seed, tiny_max):  # noqa: F811
     """the structures of tests/test_fuzz_schedule.py (random graphs, chains, arrowheads: ragged supernodes, scattered
     relative maps, a 350-column front through k_gemm128) with every factor kernel from its own source"""
