@@ -22,9 +22,9 @@ namespace mi355 {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// [host-runnable: begin] -- the kernels up to the end marker use no wave intrinsic, no LDS and no barrier; the test
-// infrastructure (tests/helpers/sched_emu.cpp) cuts this region out and executes the very same source on the
-// CPU, thread by thread, as a check that needs no GPU.  Keep it that way when editing in here.
+// The kernels from here to k_gemm64 use no wave intrinsic, no LDS and no barrier.  (The test infrastructure compiles this
+// whole file for the host against a stand-in HIP header and runs every kernel on the CPU -- tests/helpers/hipcpu,
+// tests/test_device_source_on_cpu.py; these simple ones it can run thread after thread.)
 // hardware FP64 atomic add (global_atomic_add_f64); no CAS loop
 __device__ __forceinline__ void atomic_add_f64(double *p, double v)
 {
@@ -236,8 +236,6 @@ __global__ __launch_bounds__(64 * TINY_WAVES) void k_gemm_tiny(
         else C[m + (int64_t)n * ldc] -= acc;
     }
 }
-
-// [host-runnable: end]
 
 //------------------------------------------------------------------------------
 // k_gemm64: batched C = A * B^T on v_mfma_f64_16x16x4_f64, 64x64 tile per workgroup
@@ -699,15 +697,12 @@ __global__ __launch_bounds__(256) void k_trsm64(
 // products on LDS operands (3 barriers per 16 columns instead of 3 per column), and the
 // 64x64 inverse is assembled from the 16x16 ones by MFMA block products.
 //------------------------------------------------------------------------------
-// [wave-runnable: begin] -- this helper and k_potrf16 below use v_readlane only: the test infrastructure runs them on
-// the CPU with one host thread per lane (tests/helpers/sched_emu.cpp)
 __device__ __forceinline__ double lane_bcast(double v, int srclane)      // srclane: compile-time constant
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
     return __hiloint2double(hi, lo);
 }
-// [wave-runnable: end]
 
 __global__ __launch_bounds__(256) void k_potrf64(
     const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
@@ -845,7 +840,6 @@ __global__ __launch_bounds__(256) void k_potrf64(
 // the factor goes back the same way, and lane c ends up with column c of the inverse, which is how Dinv stores it.
 // No LDS, no barrier.
 //------------------------------------------------------------------------------
-// [wave-runnable: begin]
 constexpr int POTRF16_WAVES = 4;
 
 __global__ __launch_bounds__(64 * POTRF16_WAVES) void k_potrf16(
@@ -923,6 +917,5 @@ __global__ __launch_bounds__(64 * POTRF16_WAVES) void k_potrf16(
         }
     }
 }
-// [wave-runnable: end]
 
 }  // namespace mi355
