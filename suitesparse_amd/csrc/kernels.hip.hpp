@@ -22,9 +22,7 @@ namespace mi355 {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// The kernels from here to k_gemm64 use no wave intrinsic, no LDS and no barrier.  (The test infrastructure compiles this
-// whole file for the host against a stand-in HIP header and runs every kernel on the CPU -- tests/helpers/hipcpu,
-// tests/test_device_source_on_cpu.py; these simple ones it can run thread after thread.)
+// The kernels from here to k_gemm64 use no wave intrinsic, no LDS and no barrier.
 // hardware FP64 atomic add (global_atomic_add_f64); no CAS loop
 __device__ __forceinline__ void atomic_add_f64(double *p, double v)
 {
