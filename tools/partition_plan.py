@@ -45,7 +45,9 @@ def main():
         top_entries = sum(hi - lo for lo, hi in part["top_ranges"])
         ph0 = R[:, 0].max() / (GEMM_TFLOPS * 1e12) + R[:, 3].max() * 0 + 0.0
         chain0 = R[:, 3].max() * STEP_US * 1e-6 * 0.25          # low levels: steps are short launches, not full chains
-        allred = 2.0 * top_entries * 8 * (world - 1) / max(world, 1) / (XGMI_GBS * 1e9) if world > 1 else 0.0
+        # reduce of every top block to its owner: a rank sends each block at most once (the all-reduce it replaced:
+        # 2 (N-1)/N times the volume)
+        allred = top_entries * 8 * (world - 1) / max(world, 1) / (XGMI_GBS * 1e9) if world > 1 else 0.0
         topw = R[:, 1].max() / (GEMM_TFLOPS * 1e12)
         chain1 = R[0, 4] * STEP_US * 1e-6 if world > 1 else 0.0
         bcast = R[0, 6] * 8 / (XGMI_GBS * 1e9) if world > 1 else 0.0
@@ -54,8 +56,8 @@ def main():
             t1 = total
         print(f"N={world}: phase0 flops max/mean {R[:, 0].max() / max(R[:, 0].mean(), 1):.3f} ({R[:, 0].max():.3g})  "
               f"top share max/mean {R[:, 1].max() / max(R[:, 1].mean(), 1):.3f} ({R[:, 1].max():.3g} of {R[0, 2]:.3g})  "
-              f"top chain {int(R[0, 4])} steps  bcasts {int(R[0, 5])} = {R[0, 6] * 8e-9:.1f} GB  all-reduce {top_entries * 8e-9:.1f} GB")
-        print(f"      model: phase0 {ph0 * 1e3:.0f} + {chain0 * 1e3:.0f} ms, all-reduce {allred * 1e3:.0f} ms, top gemm {topw * 1e3:.0f} ms, "
+              f"top chain {int(R[0, 4])} steps  bcasts {int(R[0, 5])} = {R[0, 6] * 8e-9:.1f} GB  reduced to owners {top_entries * 8e-9:.1f} GB")
+        print(f"      model: phase0 {ph0 * 1e3:.0f} + {chain0 * 1e3:.0f} ms, reduce {allred * 1e3:.0f} ms, top gemm {topw * 1e3:.0f} ms, "
               f"top chain {chain1 * 1e3:.0f} ms, broadcasts {bcast * 1e3:.0f} ms -> {total * 1e3:.0f} ms"
               + (f"  speedup {t1 / total:.2f}, efficiency {t1 / total / world:.2f}" if world > 1 else ""))
 
