@@ -396,3 +396,31 @@ def test_random_structure_end_to_end_through_the_abi(engine, kind, n, seed, tiny
         got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
         low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
         assert np.abs(got[low] - want[low]).max() <= 1e-10 * np.abs(Lo).max()
+
+
+def test_two_supernodes_scatter_update(engine):
+    import test_gpu_parity as t
+    t.test_two_supernodes_scatter_update(engine)
+
+
+def test_complex_solve2_with_permutation(engine):
+    """mi355_solve on a complex factor with L->Perm: complex B, and a real B under a complex L (zero imaginary part on the
+    way in), against dense algebra on the golden factor"""
+    import test_unsym as tu
+    g = load_golden("tcov_c30up")
+    n = g["n"]
+    L = engine.SupernodalFactor(sym_of(g), xtype=2)
+    assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == 0
+    L.set_perm(g["Perm"])
+    Ld = tu.dense_L(g, g["Lx"])
+    P = np.zeros((n, n))
+    P[np.arange(n), g["Perm"]] = 1.0
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    want = P.T @ np.linalg.solve(Ld @ Ld.conj().T, P @ B)
+    assert relerr(L.solve(B, 0), want) < 1e-9
+    Br = rng.standard_normal((n, 2))
+    assert relerr(L.solve(Br, 0), L.solve(Br + 0j, 0)) < 1e-14
+    assert relerr(L.solve(B, 4), np.linalg.solve(Ld, B)) < 1e-9           # CHOLMOD_L
+    assert relerr(L.solve(B, 5), np.linalg.solve(Ld.conj().T, B)) < 1e-9  # CHOLMOD_Lt
+    L.close()
