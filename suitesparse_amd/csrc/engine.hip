@@ -131,6 +131,7 @@ struct mi355_factor_s {
     double st_total = 0, st_gemm = 0, st_potrf = 0, st_asm = 0, st_solve = 0;
     double st_ngemm = 0, st_npotrf = 0, st_tiles = 0, st_nbig = 0, st_big = 0;
     EventTimer *timer = nullptr;   // events of the last profiled numeric call, collected lazily
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket of one numeric / solve call (created once: no leak on error paths)
 };
 
 namespace {
@@ -148,6 +149,7 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
         // no task may point outside the arrays the kernels index with it (a GPU memory fault takes the machine down)
         // (Dinv is sized by the full schedule: all blocks)
         const std::string bad = check_schedule_bounds(F->sym, S, nullptr, std::max<int64_t>(S.dinv_size, F->full.sched.dinv_size));
+        if (bad.compare(0, 10, "too large:") == 0) return fail(MI355_TOO_LARGE, bad);
         if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: schedule rejected before upload: " + bad);
     }
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
@@ -181,15 +183,22 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
 }
 
 struct EventTimer {
-    hipEvent_t a = nullptr, b = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];   // 0 gemm64 1 potrf 2 asm 3 gemm128
+    std::vector<hipEvent_t> pool;                           // events of earlier calls, reused: none is created
+                                                            // inside a timed step once the first profiled call has run
     bool on = false;
     hipStream_t st = nullptr;
+    hipEvent_t get()
+    {
+        hipEvent_t x = nullptr;
+        if (!pool.empty()) { x = pool.back(); pool.pop_back(); }
+        else (void)hipEventCreate(&x);
+        return x;
+    }
     void begin(int kind, hipStream_t on_stream = nullptr)
     {
         if (!on) return;
-        hipEvent_t x, y;
-        (void)hipEventCreate(&x); (void)hipEventCreate(&y);
+        hipEvent_t x = get(), y = get();
         (void)hipEventRecord(x, on_stream ? on_stream : st);
         ev[kind].push_back({x, y});
     }
@@ -202,10 +211,15 @@ struct EventTimer {
     void drop()
     {
         for (int k = 0; k < 4; k++) {
-            for (auto &p : ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+            for (auto &p : ev[k]) { pool.push_back(p.first); pool.push_back(p.second); }
             ev[k].clear();
         }
         pending = false;
+    }
+    void destroy_pool()
+    {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
     }
     double collect(int kind)
     {
@@ -215,7 +229,7 @@ struct EventTimer {
             (void)hipEventSynchronize(p.second);
             (void)hipEventElapsedTime(&t, p.first, p.second);
             ms += t;
-            (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+            pool.push_back(p.first); pool.push_back(p.second);
         }
         ev[kind].clear();
         return ms;
@@ -422,6 +436,8 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
         HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));
         HIP_TRY(hipStreamCreateWithPriority(&F->stream, hipStreamNonBlocking, phi));
         HIP_TRY(hipStreamCreateWithPriority(&F->side, hipStreamNonBlocking, plo));
+        HIP_TRY(hipEventCreate(&F->ev0));
+        HIP_TRY(hipEventCreate(&F->ev1));
     }
 
     F->Super.assign(Super, Super + (nsuper > 0 ? nsuper + 1 : 0));
@@ -464,7 +480,9 @@ int mi355_factor_free(mi355_factor *F)
     if (F->side) { (void)hipStreamSynchronize(F->side); (void)hipStreamDestroy(F->side); }
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
     for (hipEvent_t ev : F->side_ev) (void)hipEventDestroy(ev);
-    if (F->timer) { F->timer->drop(); delete F->timer; }
+    if (F->ev0) (void)hipEventDestroy(F->ev0);
+    if (F->ev1) (void)hipEventDestroy(F->ev1);
+    if (F->timer) { F->timer->drop(); F->timer->destroy_pool(); delete F->timer; }
     delete F->part_local;
     delete F->part_top;
     delete F->part_dist;
@@ -588,6 +606,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
     const Symbolic &S = F->sym;
     F->numeric_ok = false;
+    F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
     if (S.n == 0 || S.nsuper == 0) {
         F->minor = S.n; F->numeric_ok = true;
@@ -600,9 +619,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     tm.drop();
     tm.on = F->profile != 0;
     tm.st = F->stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    const hipEvent_t e0 = F->ev0, e1 = F->ev1;
     HIP_TRY(hipEventRecord(e0, F->stream));
 
     rc = run_schedule(F, F->full, S.n, beta_re, tm);
@@ -643,7 +660,6 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     F->st_total = ms;
     tm.pending = tm.on;
     F->minor = minor_out;
@@ -860,9 +876,7 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     if (phase == 0) { tm.drop(); F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0; }
     tm.on = F->profile != 0;
     tm.st = F->stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    const hipEvent_t e0 = F->ev0, e1 = F->ev1;
     HIP_TRY(hipEventRecord(e0, F->stream));
     rc = run_schedule(F, phase == 0 ? *F->part_local : *F->part_top, S.n, beta_re, tm, F->asm_mask.p, phase == 0);
     if (rc) return rc;
@@ -878,7 +892,6 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     F->st_total = (phase == 0 ? 0.0 : F->st_total) + ms;
     tm.pending = tm.on;
     if (sf != big) {
@@ -949,9 +962,7 @@ int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64
     EventTimer &tm = *F->timer;
     tm.on = F->profile != 0;
     tm.st = F->stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    const hipEvent_t e0 = F->ev0, e1 = F->ev1;
     HIP_TRY(hipEventRecord(e0, F->stream));
     if (seg == 0) {
         // the block inverses of the blocks other ranks own stay zero: a sum over the ranks completes them
@@ -976,7 +987,6 @@ int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     F->st_total += ms;
     tm.pending = tm.on;
     if (seg == nb) {
@@ -1026,9 +1036,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     DeviceSchedule &DS = part ? *part : F->full;
     const std::vector<Step> &steps = DS.sched.steps;
     const PotrfTask *P = DS.potrf.p;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    const hipEvent_t e0 = F->ev0, e1 = F->ev1;
     HIP_TRY(hipEventRecord(e0, F->stream));
     const int nr = (int)nrhs;
     const bool cplx = F->E == 2;
@@ -1081,7 +1089,6 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         HIP_TRY(hipEventSynchronize(e1));
         float gms = 0;
         HIP_TRY(hipEventElapsedTime(&gms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         F->st_solve = gms;
         return MI355_OK;
     }
@@ -1234,7 +1241,6 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     F->st_solve = ms;
     return MI355_OK;
 }
@@ -1519,7 +1525,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 12) tuning().lookahead = value;
     else if (key == 13) tuning().solve_bwd_div_mma = std::max(1, value);
     else if (key == 14) tuning().tiny_max = std::max(0, value);
-    else if (key == 14) tuning().solve_fwd_div_mma = std::max(1, value);
+    else if (key == 15) tuning().solve_fwd_div_mma = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -615,6 +615,15 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
     for (size_t i = 0; i < sc.gemm.size(); i++) {
         const GemmTask &t = sc.gemm[i];
         if (t.M <= 0 || t.N <= 0 || t.K <= 0 || t.lda < t.M || t.ldc <= 0) return bad("gemm task shape", (int64_t)i);
+        {
+            // TileEntry packs the tile row and column into 16 bits each (more than 4.19 M rows of one task with
+            // 64-row tiles): a wider task would wrap and compute some tiles twice, others never
+            const int tr = tile_rows(t.big), tc = tile_cols(t.big);
+            if (((int64_t)t.M + tr - 1) / tr > 65536 || ((int64_t)t.N + tc - 1) / tc > 65536) {
+                snprintf(buf, sizeof buf, "too large: gemm task %lld has more than 65536 tile rows or columns", (long long)i);
+                return std::string(buf);
+            }
+        }
         if (t.a_off < 0 || last(t.a_off, t.M, t.K, t.lda) >= xs) return bad("gemm task A", (int64_t)i);
         if (t.mode == GEMM_OVERWRITE) {
             if (t.b_off < 0 || last(t.b_off, t.N, t.K, t.ldb) >= ds) return bad("gemm task B (Dinv)", (int64_t)i);

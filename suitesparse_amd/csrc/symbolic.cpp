@@ -1,7 +1,9 @@
 // symbolic.cpp -- host symbolic analysis (include/mi355_symbolic.h).  Pure C++.
-// Integer restatement of the reference's analysis chain for a GIVEN permutation; each
-// step cites the reference code it follows.  Verified bit-exact against the reference
-// (cholmod_l_analyze with CHOLMOD_GIVEN) in tests/test_symbolic.py.
+// For a GIVEN permutation it produces the structure the reference's analysis chain produces (Perm after the
+// weighted postorder, ColCount, Super, Lpi, Lpx, Ls, maxcsize, maxesize, fl, lnz), verified bit-exact against
+// cholmod_l_analyze with CHOLMOD_GIVEN in tests/test_symbolic.py.  The OUTPUT is pinned by the reference; the
+// algorithms are formulated here: compressed child tables with cursors for the postorders, supernode chains and a
+// contiguous-range amalgamation sweep, bottom-up union of the children's structures for the row lists.
 #include "../../include/mi355_symbolic.h"
 #include "../../include/mi355_cholmod.h"
 #include <algorithm>
@@ -85,50 +87,55 @@ void etree(Int n, const Csc &U, std::vector<Int> &parent)
         }
 }
 
-// cholmod_postorder.c:131-300 (non-recursive dfs :60-95), optional weights
-Int postorder(Int n, const std::vector<Int> &Parent, const Int *Weight, std::vector<Int> &Post)
+// Postorder of the forest `parent`, children visited by ascending key (key = weight clamped to [0, n-1], or none),
+// ties by ascending index; roots by ascending index.  That is the order cholmod_postorder produces
+// (CHOLMOD/Cholesky/cholmod_postorder.c: its bucket lists come out as exactly this ordering of siblings), here
+// through a child table in compressed form: nodes are bucket-sorted by key once (stable in the index), dealt to
+// their parents' slots in that order, and the walk keeps one cursor per open node.
+Int postorder(Int n, const std::vector<Int> &parent, const Int *weight, std::vector<Int> &post)
 {
-    std::vector<Int> Head(n + 1, EMPTY), Next(n, EMPTY), Pstack(n + 1, EMPTY);
-    Post.assign(n, 0);
-    if (!Weight) {
-        for (Int j = n - 1; j >= 0; j--) {
-            const Int p = Parent[j];
-            if (p >= 0 && p < n) { Next[j] = Head[p]; Head[p] = j; }
-        }
+    post.assign((size_t)n, 0);
+    // nodes in sibling order
+    std::vector<Int> order((size_t)n);
+    if (!weight) {
+        for (Int j = 0; j < n; j++) order[(size_t)j] = j;
     } else {
-        std::vector<Int> &Whead = Pstack;
-        for (Int w = 0; w < n; w++) Whead[w] = EMPTY;
-        for (Int j = 0; j < n; j++) {
-            const Int p = Parent[j];
-            if (p >= 0 && p < n) {
-                Int w = Weight[j];
-                w = std::max<Int>(0, w);
-                w = std::min<Int>(w, n - 1);
-                Next[j] = Whead[w];
-                Whead[w] = j;
+        std::vector<Int> slot((size_t)n + 1, 0);
+        auto key = [&](Int j) { return std::min<Int>(std::max<Int>(weight[j], 0), n - 1); };
+        for (Int j = 0; j < n; j++) slot[(size_t)key(j) + 1]++;
+        for (Int w = 0; w < n; w++) slot[(size_t)w + 1] += slot[(size_t)w];
+        for (Int j = 0; j < n; j++) order[(size_t)slot[(size_t)key(j)]++] = j;
+    }
+    // child table: kids[kid_lo[p] .. kid_lo[p+1]) in sibling order
+    std::vector<Int> kid_lo((size_t)n + 1, 0), kids((size_t)n);
+    auto has_parent = [&](Int j) { return parent[(size_t)j] >= 0 && parent[(size_t)j] < n; };
+    for (Int j = 0; j < n; j++) if (has_parent(j)) kid_lo[(size_t)parent[(size_t)j] + 1]++;
+    for (Int p = 0; p < n; p++) kid_lo[(size_t)p + 1] += kid_lo[(size_t)p];
+    {
+        std::vector<Int> fill(kid_lo.begin(), kid_lo.end() - 1);
+        for (Int j : order) if (has_parent(j)) kids[(size_t)fill[(size_t)parent[(size_t)j]]++] = j;
+    }
+    // walk: a node is numbered when its cursor has run past its last child
+    std::vector<Int> open, cursor((size_t)n);
+    open.reserve(64);
+    Int count = 0;
+    for (Int r = 0; r < n; r++) {
+        if (parent[(size_t)r] != EMPTY) continue;
+        cursor[(size_t)r] = kid_lo[(size_t)r];
+        open.push_back(r);
+        while (!open.empty()) {
+            const Int v = open.back();
+            if (cursor[(size_t)v] < kid_lo[(size_t)v + 1]) {
+                const Int c = kids[(size_t)cursor[(size_t)v]++];
+                cursor[(size_t)c] = kid_lo[(size_t)c];
+                open.push_back(c);
+            } else {
+                post[(size_t)count++] = v;
+                open.pop_back();
             }
         }
-        for (Int w = n - 1; w >= 0; w--)
-            for (Int j = Whead[w], nextj; j != EMPTY; j = nextj) {
-                nextj = Next[j];
-                const Int p = Parent[j];
-                Next[j] = Head[p];
-                Head[p] = j;
-            }
     }
-    Int k = 0;
-    for (Int j = 0; j < n; j++) {
-        if (Parent[j] != EMPTY) continue;
-        Int phead = 0;
-        Pstack[0] = j;
-        while (phead >= 0) {
-            const Int p = Pstack[phead];
-            const Int c = Head[p];
-            if (c == EMPTY) { phead--; Post[k++] = p; }
-            else { Head[p] = Next[c]; Pstack[++phead] = c; }
-        }
-    }
-    return k;
+    return count;
 }
 
 // column counts of L (Gilbert-Ng-Peyton skeleton algorithm; the values are unique, so they
@@ -165,23 +172,6 @@ void colcounts(Int n, const Csc &S, const std::vector<Int> &parent, const std::v
     for (Int k = 0; k < n; k++) {
         const Int j = post[k];      // children before parents
         if (parent[j] != EMPTY) cc[parent[j]] += cc[j];
-    }
-}
-
-// cholmod_super_symbolic.c:76-127
-inline void subtree(Int k, const Csc &U, const std::vector<Int> &SuperMap, const std::vector<Int> &Sparent,
-                    Int mark, Int k1, std::vector<Int> &Flag, std::vector<Int> &Ls, std::vector<Int> &Lpi2)
-{
-    for (Int p = U.p[k]; p < U.p[k + 1]; p++) {
-        const Int i = U.i[p];
-        if (i < k1) {
-            for (Int si = SuperMap[i]; Flag[si] < mark; si = Sparent[si]) {
-                Ls[Lpi2[si]++] = k;
-                Flag[si] = mark;
-            }
-        } else {
-            break;      // columns of U are sorted
-        }
     }
 }
 
@@ -290,122 +280,142 @@ int mi355_symbolic_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, cons
     }
     for (Int k = 0; k < n; k++) pinv[Perm[k]] = k;
     permute_lower(n, Ap, Ai, nullptr, pinv.data(), S);
-    transpose(n, S, U, false);
     R->snnz = S.p[n];
 
-    // ---- cholmod_super_symbolic2 (cholmod_super_symbolic.c:391-928), for_whom = Cholesky, no GPU caps
-    std::vector<Int> Wi(n, 0), SuperMap(n), Sparent(n), Snz(n), Merged(n), Zeros(n), Super(n + 1);
-    for (Int j = 0; j < n; j++) if (Parent[j] != EMPTY) Wi[Parent[j]]++;
-    Int nfsuper = 1;
-    Super[0] = 0;
-    for (Int j = 1; j < n; j++)
-        if (Parent[j - 1] != j || ColCount[j - 1] != ColCount[j] + 1 || Wi[j] > 1) Super[nfsuper++] = j;
-    Super[nfsuper] = n;
-    std::vector<Int> &Nscol = Wi;
-    for (Int s = 0; s < nfsuper; s++)
-        for (Int k = Super[s]; k < Super[s + 1]; k++) SuperMap[k] = s;
-    for (Int s = 0; s < nfsuper; s++) {
-        const Int parent = Parent[Super[s + 1] - 1];
-        Sparent[s] = (parent == EMPTY) ? EMPTY : SuperMap[parent];
-    }
-    for (Int s = 0; s < nfsuper; s++) {
-        Merged[s] = EMPTY;
-        Nscol[s] = Super[s + 1] - Super[s];
-        Zeros[s] = 0;
-        Snz[s] = ColCount[Super[s]];
-    }
-    const double Int_max = (double)std::numeric_limits<Int>::max();
-    for (Int s = nfsuper - 2; s >= 0; s--) {
-        Int ss = Sparent[s];
-        if (ss == EMPTY) continue;
-        for (ss = Sparent[s]; Merged[ss] != EMPTY; ss = Merged[ss]) {}
-        const Int sparent = ss;
-        for (Int t = Sparent[s], snext; Merged[t] != EMPTY; t = snext) { snext = Merged[t]; Merged[t] = sparent; }
-        if (sparent != s + 1) continue;
-        const Int nscol0 = Nscol[s], nscol1 = Nscol[s + 1], ns = nscol0 + nscol1;
-        Int totzeros = Zeros[s + 1];
-        const double lnz1 = (double)Snz[s + 1];
-        bool merge;
-        if (ns <= nrelax[0]) {
-            merge = true;
-        } else {
-            const double lnz0 = (double)Snz[s];
-            const double xnewzeros = nscol0 * (lnz1 + nscol0 - lnz0);
-            const Int newzeros = nscol0 * (Snz[s + 1] + nscol0 - Snz[s]);
-            if (xnewzeros == 0) {
-                merge = true;
-            } else {
-                const double xtotzeros = ((double)totzeros) + xnewzeros;
-                const double xns = (double)ns;
-                const double xtotsize = (xns * (xns + 1) / 2) + xns * (lnz1 - nscol1);
-                const double z = xtotzeros / xtotsize;
-                totzeros += newzeros;
-                merge = ((ns <= nrelax[1] && z < zrelax[0]) || (ns <= nrelax[2] && z < zrelax[1]) || (z < zrelax[2]))
-                        && (xtotsize < Int_max / sizeof(double));
-            }
+    // ---- supernodes.  What must come out is what cholmod_super_symbolic2 computes for this (Parent, ColCount)
+    // (CHOLMOD/Supernodal/cholmod_super_symbolic.c, for_whom = Cholesky, no GPU caps); how it is computed is ours:
+    //   * chains: column j continues the supernode of j-1 iff j is the parent of j-1, its only child, and
+    //     their structures nest (one row fewer) -- the fundamental supernodes;
+    //   * relaxed amalgamation as a right-to-left sweep over CONTIGUOUS groups: a fundamental supernode can only
+    //     ever be absorbed by its left neighbour, so every group is a range [lead, end) of fundamental supernodes and
+    //     "the group of s's parent is led by s+1" is just  parent(s) < end(s+1)  -- no merge forest is needed;
+    //   * row structures bottom-up: struct(s) = own columns + rows of S below them + the children's structures
+    //     beyond the own columns (children precede parents), collected with a marker and sorted.
+    struct Group { Int first_col, ncols, nrows, zeros, end; };    // end: one past the last fundamental supernode
+    std::vector<Group> G;
+    std::vector<Int> fparent;                                     // parent of a fundamental supernode (index into G)
+    {
+        std::vector<Int> nkids((size_t)n, 0), fund_of((size_t)n);
+        for (Int j = 0; j < n; j++) if (Parent[j] != EMPTY) nkids[(size_t)Parent[j]]++;
+        for (Int j = 0; j < n; j++) {
+            const bool chain = j > 0 && Parent[j - 1] == j && nkids[(size_t)j] <= 1 && ColCount[j - 1] == ColCount[j] + 1;
+            if (chain) G.back().ncols++;
+            else G.push_back(Group{j, 1, ColCount[j], 0, (Int)G.size() + 1});
+            fund_of[(size_t)j] = (Int)G.size() - 1;
         }
-        if (merge) {
-            Zeros[s] = totzeros;
-            Merged[s + 1] = s;
-            Snz[s] = nscol0 + Snz[s + 1];
-            Nscol[s] += Nscol[s + 1];
+        fparent.resize(G.size());
+        for (size_t f = 0; f < G.size(); f++) {
+            const Int top = Parent[G[f].first_col + G[f].ncols - 1];
+            fparent[f] = (top == EMPTY) ? EMPTY : fund_of[(size_t)top];
         }
     }
-    Int nsuper = 0;
-    for (Int s = 0; s < nfsuper; s++)
-        if (Merged[s] == EMPTY) { Super[nsuper] = Super[s]; Snz[nsuper] = Snz[s]; nsuper++; }
-    Super[nsuper] = n;
-    for (Int s = 0; s < nsuper; s++)
-        for (Int k = Super[s]; k < Super[s + 1]; k++) SuperMap[k] = s;
+    // absorb(c, p): may group c take in its right neighbour p (c's parent group)?  On yes, zeros_out = explicit
+    // zeros the merged supernode is accounted with.  The arithmetic (incl. which branches do NOT add the new zeros)
+    // follows the reference's decision exactly, since the structure must be bit-identical to CHOLMOD's.
+    const double entry_cap = (double)std::numeric_limits<Int>::max() / sizeof(double);
+    auto absorb = [&](const Group &c, const Group &p, Int &zeros_out) {
+        const Int width = c.ncols + p.ncols;
+        zeros_out = p.zeros;
+        if (width <= nrelax[0]) return true;
+        // columns of c are padded down to p's structure: per column (rows of p + ncols of c) - rows of c
+        const double pad = (double)c.ncols * ((double)p.nrows + (double)c.ncols - (double)c.nrows);
+        if (pad == 0) return true;
+        const double w = (double)width;
+        const double entries = w * (w + 1) / 2 + w * ((double)p.nrows - (double)p.ncols);
+        const double frac = ((double)p.zeros + pad) / entries;
+        zeros_out = p.zeros + c.ncols * (p.nrows + c.ncols - c.nrows);
+        const bool sparse_enough = (width <= nrelax[1] && frac < zrelax[0]) || (width <= nrelax[2] && frac < zrelax[1]) ||
+                                   frac < zrelax[2];
+        return sparse_enough && entries < entry_cap;
+    };
+    const Int nfund = (Int)G.size();
+    std::vector<uint8_t> absorbed((size_t)nfund, 0);
+    for (Int f = nfund - 2; f >= 0; f--) {
+        if (fparent[(size_t)f] == EMPTY || fparent[(size_t)f] >= G[(size_t)f + 1].end) continue;   // parent not in the next group
+        Int z = 0;
+        if (!absorb(G[(size_t)f], G[(size_t)f + 1], z)) continue;
+        Group &c = G[(size_t)f];
+        const Group &p = G[(size_t)f + 1];
+        c.nrows = c.ncols + p.nrows;
+        c.ncols += p.ncols;
+        c.zeros = z;
+        c.end = p.end;
+        absorbed[(size_t)f + 1] = 1;
+    }
+    std::vector<Int> Super, SuperMap((size_t)n), Sparent;
+    R->Lpi.assign(1, 0);
+    R->Lpx.assign(1, 0);
+    for (Int f = 0; f < nfund; f++) {
+        if (absorbed[(size_t)f]) continue;
+        const Group &g = G[(size_t)f];
+        const Int s = (Int)Super.size();
+        Super.push_back(g.first_col);
+        for (Int k = g.first_col; k < g.first_col + g.ncols; k++) SuperMap[(size_t)k] = s;
+        R->Lpi.push_back(R->Lpi.back() + g.nrows);
+        R->Lpx.push_back(R->Lpx.back() + g.ncols * g.nrows);
+    }
+    const Int nsuper = (Int)Super.size();
+    Super.push_back(n);
+    Sparent.assign((size_t)nsuper, EMPTY);
     for (Int s = 0; s < nsuper; s++) {
-        const Int parent = Parent[Super[s + 1] - 1];
-        Sparent[s] = (parent == EMPTY) ? EMPTY : SuperMap[parent];
+        const Int top = Parent[Super[(size_t)s + 1] - 1];
+        if (top != EMPTY) Sparent[(size_t)s] = SuperMap[(size_t)top];
     }
     R->nsuper = nsuper;
-    R->Super.assign(Super.begin(), Super.begin() + nsuper + 1);
-    R->Lpi.resize(nsuper + 1);
-    R->Lpx.resize(nsuper + 1);
-    Int ps = 0, px = 0;
-    for (Int s = 0; s < nsuper; s++) {
-        R->Lpi[s] = ps; R->Lpx[s] = px;
-        ps += Snz[s];
-        px += (Super[s + 1] - Super[s]) * Snz[s];
-    }
-    R->Lpi[nsuper] = ps; R->Lpx[nsuper] = px;
-    R->ssize = std::max<Int>(1, ps);
-    R->xsize = std::max<Int>(1, px);
-    R->Ls.assign(R->ssize, 0);
+    R->Super = Super;
+    R->ssize = std::max<Int>(1, R->Lpi.back());
+    R->xsize = std::max<Int>(1, R->Lpx.back());
+    R->Ls.assign((size_t)R->ssize, 0);
     {
-        std::vector<Int> Lpi2(R->Lpi.begin(), R->Lpi.end() - 1), Flag(nsuper, EMPTY);
-        Int mark = 0;
-        for (Int s = 0; s < nsuper; s++) {
-            const Int k1 = Super[s], k2 = Super[s + 1];
-            for (Int k = k1; k < k2; k++) R->Ls[Lpi2[s]++] = k;
-            for (Int k = k1; k < k2; k++) {
-                mark++;
-                Flag[s] = mark;
-                subtree(k, U, SuperMap, Sparent, mark, k1, Flag, R->Ls, Lpi2);
-            }
+        // child table of the supernodal tree, then the bottom-up union
+        std::vector<Int> kid_lo((size_t)nsuper + 1, 0), kids((size_t)nsuper);
+        for (Int s = 0; s < nsuper; s++) if (Sparent[(size_t)s] != EMPTY) kid_lo[(size_t)Sparent[(size_t)s] + 1]++;
+        for (Int s = 0; s < nsuper; s++) kid_lo[(size_t)s + 1] += kid_lo[(size_t)s];
+        {
+            std::vector<Int> fill(kid_lo.begin(), kid_lo.end() - 1);
+            for (Int s = 0; s < nsuper; s++) if (Sparent[(size_t)s] != EMPTY) kids[(size_t)fill[(size_t)Sparent[(size_t)s]]++] = s;
         }
-        for (Int s = 0; s < nsuper; s++)
-            if (Lpi2[s] != R->Lpi[s + 1]) { delete R; return MI355_INVALID; }   // ColCount inconsistent
+        std::vector<Int> seen_by((size_t)n, EMPTY);
+        for (Int s = 0; s < nsuper; s++) {
+            const Int k1 = Super[(size_t)s], k2 = Super[(size_t)s + 1];
+            Int *rows = R->Ls.data() + R->Lpi[(size_t)s];
+            const Int cap = R->Lpi[(size_t)s + 1] - R->Lpi[(size_t)s];
+            Int cnt = 0;
+            for (Int k = k1; k < k2; k++) rows[cnt++] = k;
+            auto take = [&](Int i) {
+                if (i < k2 || seen_by[(size_t)i] == s) return true;
+                if (cnt >= cap) return false;
+                seen_by[(size_t)i] = s;
+                rows[cnt++] = i;
+                return true;
+            };
+            bool fits = true;
+            for (Int k = k1; k < k2 && fits; k++)
+                for (Int q = S.p[(size_t)k]; q < S.p[(size_t)k + 1] && fits; q++) fits = take(S.i[(size_t)q]);
+            for (Int c = kid_lo[(size_t)s]; c < kid_lo[(size_t)s + 1] && fits; c++) {
+                const Int kid = kids[(size_t)c];
+                const Int *lo = R->Ls.data() + R->Lpi[(size_t)kid] + (Super[(size_t)kid + 1] - Super[(size_t)kid]);
+                const Int *hi = R->Ls.data() + R->Lpi[(size_t)kid + 1];
+                for (const Int *r = std::lower_bound(lo, hi, k2); r < hi && fits; r++) fits = take(*r);
+            }
+            if (!fits || cnt != cap) { delete R; return MI355_INVALID; }        // column counts inconsistent with the pattern
+            std::sort(rows + (k2 - k1), rows + cnt);
+        }
     }
-    // maxcsize / maxesize (:889-923)
+    // largest update workspace any descendant would need in the reference (Common->maxcsize: rows from its first row
+    // in an ancestor to its end, times its rows inside that ancestor) and the longest sub-diagonal row list (maxesize)
     Int maxcsize = 1, maxesize = 1;
     for (Int d = 0; d < nsuper; d++) {
-        const Int nscol = Super[d + 1] - Super[d];
-        Int p = R->Lpi[d] + nscol, plast = p;
-        const Int pend = R->Lpi[d + 1];
-        maxesize = std::max(maxesize, pend - p);
-        Int slast = (p == pend) ? EMPTY : SuperMap[R->Ls[p]];
-        for (; p <= pend; p++) {
-            const Int s = (p == pend) ? EMPTY : SuperMap[R->Ls[p]];
-            if (s != slast) {
-                const Int ndrow1 = p - plast, ndrow2 = pend - plast;
-                maxcsize = std::max(maxcsize, ndrow2 * ndrow1);
-                plast = p;
-                slast = s;
-            }
+        const Int *rows = R->Ls.data();
+        const Int stop = R->Lpi[(size_t)d + 1];
+        Int at = R->Lpi[(size_t)d] + (Super[(size_t)d + 1] - Super[(size_t)d]);
+        maxesize = std::max(maxesize, stop - at);
+        while (at < stop) {
+            const Int anc = SuperMap[(size_t)rows[at]];
+            Int run_end = at + 1;
+            while (run_end < stop && SuperMap[(size_t)rows[run_end]] == anc) run_end++;
+            maxcsize = std::max(maxcsize, (stop - at) * (run_end - at));
+            at = run_end;
         }
     }
     R->maxcsize = maxcsize;

@@ -93,3 +93,38 @@ def test_invalid_inputs():
     Ai[p["Ap"][3]] = 0
     with pytest.raises(engine.Mi355Error):
         symbolic.analyze(p["n"], p["Ap"], Ai, None)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_symbolic_vs_live_reference_on_irregular_graphs(seed, have_ref):
+    """random sparse symmetric patterns (no grid regularity: forests, dense rows, isolated vertices) under random
+    permutations: the chain / contiguous-range amalgamation / bottom-up row structures of symbolic.cpp against
+    cholmod_l_analyze (CHOLMOD_GIVEN), bit for bit"""
+    if not have_ref:
+        pytest.skip("oracle/_ref not available")
+    import scipy.sparse as sp
+    from oracle.refcholmod import RefCholmod
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 400))
+    dens = [0.002, 0.01, 0.03, 0.1][seed % 4]
+    M = sp.random(n, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+    if seed % 3 == 0 and n > 10:                        # a few dense rows/columns
+        M = sp.lil_matrix(M)
+        for r in rng.integers(0, n, 2):
+            M[r, rng.integers(0, n, n // 3)] = 1.0
+        M = sp.csc_matrix(M)
+    A = sp.tril(M + M.T, -1) + sp.identity(n) * (n + 1.0)
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    Ap, Ai, Ax = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+    perm = rng.permutation(n).astype(np.int64)
+    sym = symbolic.analyze(n, Ap, Ai, perm)
+    r = RefCholmod()
+    r.load(n, Ap, Ai, Ax, -1)
+    inf = r.analyze(perm=perm)
+    rs = r.symbolic()
+    for k in KEYS:
+        assert np.array_equal(sym[k], rs[k]), k
+    for k in SIZES:
+        assert sym[k] == rs[k], k
+    assert sym["fl"] == inf["fl"] and sym["lnz"] == inf["lnz"]
