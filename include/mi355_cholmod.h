@@ -276,7 +276,8 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * backward solve updates (scalar / MFMA kernels) = step tiles / value; key 12: 1 = look-ahead (far part of the outermost trailing updates on
  * a second stream, measured +1.6 % at 150^3, off by default); key 14: update tasks of at most one 64 x 64 tile with
  * M*N*K <= value run one wave per task (k_gemm_tiny) instead of one workgroup per task (0 = off, the default: not
- * measured on the device yet); keys 3 and 6: retired. */
+ * measured on the device yet); key 15: forward MFMA solve updates walk step tiles / value table entries per
+ * workgroup (default 4096); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

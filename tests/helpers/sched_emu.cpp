@@ -306,6 +306,26 @@ int emu_schedule_classes(int64_t n, int64_t nsuper, const int64_t *Super, const 
     return 0;
 }
 
+// check_schedule_bounds on ONE hand-made trailing-update task of M x N (big: tile class) inside a factor large enough
+// to hold it: 1 if it is rejected as "too large" (more tile rows / columns than the 16-bit fields of a TileEntry
+// hold), 0 if accepted, -1 if rejected for another reason
+int emu_check_wide_task(int64_t M, int64_t N, int big)
+{
+    Symbolic S;
+    int64_t lpi[2] = {0, 0};
+    S.n = M; S.nsuper = 1; S.Lpi = lpi;
+    S.xsize = M * (N + 1) + M;
+    Schedule sc;
+    GemmTask t;
+    t.a_off = 0; t.b_off = 0; t.c_off = M; t.rm_off = -1;
+    t.lda = (int32_t)M; t.ldb = (int32_t)M; t.ldc = (int32_t)M;
+    t.M = (int32_t)M; t.N = (int32_t)N; t.K = 1; t.mode = GEMM_DIRECT_SUB; t.big = big; t.tile0 = 0;
+    sc.gemm.push_back(t);
+    const std::string e = check_schedule_bounds(S, sc);
+    if (e.empty()) return 0;
+    return e.compare(0, 10, "too large:") == 0 ? 1 : -1;
+}
+
 // returns 0, or <0 on schedule inconsistency; status/minor as the engine reports them
 int emu_super_numeric_f(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
                         const int64_t *Ls, int64_t ssize, int64_t xsize, const int64_t *Ap, const int64_t *Ai,

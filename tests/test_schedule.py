@@ -214,3 +214,13 @@ def test_schedule_large_supernodes_vs_oracle(emu, have_ref):
     st, minor, Lx, _ = run_emu(emu, g)
     assert st == 0 and minor == p["n"]
     assert relerr(Lx, r.Lx()) < 1e-12
+
+
+def test_task_wider_than_the_tile_fields_is_rejected(emu):
+    """TileEntry packs tile row and column into 16 bits each: a task with more than 65536 tile rows (4.19 M rows of
+    64, 8.39 M of 128) must be refused (MI355_TOO_LARGE through upload_schedule), never wrapped"""
+    emu.emu_check_wide_task.argtypes = [C.c_int64, C.c_int64, C.c_int]
+    assert emu.emu_check_wide_task(65536 * 64, 64, 0) == 0
+    assert emu.emu_check_wide_task(65536 * 64 + 1, 64, 0) == 1
+    assert emu.emu_check_wide_task(65536 * 128, 128, 1) == 0
+    assert emu.emu_check_wide_task(65536 * 128 + 1, 128, 1) == 1
