@@ -1,0 +1,50 @@
+/* cholmod_mi355.h -- the CHOLMOD side of the drop-in: the four calls a CHOLMOD build adds to route its supernodal
+ * numeric factorization and supernodal triangular solves to libmi355_cholmod.so (include/mi355_cholmod.h).
+ *
+ * Implemented in suitesparse_amd/csrc/cholmod_mi355.c, which is compiled INTO CHOLMOD (it includes cholmod.h) with
+ * -DCHOLMOD_HAS_MI355; INTEGRATION.md lists the insertion points, oracle/build_ref_mi355.sh applies exactly those
+ * insertions to a build of the reference and tests/test_cholmod_dropin.py runs cholmod_l_analyze /
+ * cholmod_l_factorize / cholmod_l_solve through it.  int64 (cholmod_l_*) and double only, like the reference's own
+ * GPU path (CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:174); everything else stays on the CPU workers.
+ */
+#ifndef CHOLMOD_MI355_H
+#define CHOLMOD_MI355_H
+
+#include "cholmod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Inserted in cholmod_l_super_symbolic2 where a build without CUDA sets Common->useGPU = 0
+ * (CHOLMOD/Supernodal/cholmod_super_symbolic.c:317-320): the reference's selection logic of :239-315 for this
+ * device -- Common->useGPU == EMPTY asks the environment (CHOLMOD_USE_GPU), a request is confirmed by
+ * mi355_probe() (replaces cholmod_l_gpu_probe), the outcome is cached in L->useGPU.  No device memory is
+ * reserved here (replaces cholmod_l_gpu_allocate: the factor handle allocates what it needs). */
+void cholmod_mi355_select (cholmod_sparse *A, int for_whom, cholmod_factor *L, cholmod_common *Common) ;
+
+/* Inserted in cholmod_l_super_numeric before the worker switch (CHOLMOD/Supernodal/cholmod_super_numeric.c:295):
+ * returns TRUE if the call was taken over -- *ok is then cholmod_super_numeric's return value, L->x, L->minor and
+ * Common->status are set as the worker would (t_cholmod_super_numeric_worker.c:1084-1146,1269) -- and FALSE if the
+ * CPU worker must run (GPU not selected, single precision). */
+int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2], cholmod_factor *L,
+    cholmod_common *Common, int *ok) ;
+
+/* Inserted in cholmod_l_super_lsolve / _ltsolve before their worker switches
+ * (CHOLMOD/Supernodal/cholmod_super_solve.c:114, :215): lower != 0 solves L x = b, else L' x = b, in X.
+ * Returns TRUE if taken over (*ok = the return value), FALSE if L has no device image. */
+int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, cholmod_common *Common, int *ok) ;
+
+/* Inserted where a factor loses its supernodal arrays: cholmod_l_to_simplicial_sym
+ * (CHOLMOD/Utility/t_cholmod_free_factor.c:22, reached from cholmod_l_free_factor and cholmod_l_change_factor) and
+ * super_num_to_simplicial_num (CHOLMOD/Utility/t_cholmod_change_factor.c:1046).  Destroys the device image of L,
+ * if any (replaces cholmod_l_gpu_deallocate for this factor). */
+void cholmod_mi355_forget (cholmod_factor *L) ;
+
+/* number of factors that currently have a device image (tests: teardown really happens) */
+int cholmod_mi355_live_handles (void) ;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

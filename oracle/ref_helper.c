@@ -418,3 +418,50 @@ int ref_solve (void *hv, int64_t nrhs, const double *Bx, double *Xx)
     cholmod_l_free_dense (&X, &h->cm) ;
     return 0 ;
 }
+
+// ---- drop-in build only (oracle/build_ref_mi355.sh: the same helper linked to libcholmod_mi355.so) --------------------
+// Common->useGPU before the next analyze: 1 request the device, 0 CPU workers, -1 ask the environment (CHOLMOD_USE_GPU)
+void ref_set_use_gpu (void *hv, int use) { ((ref_ctx *) hv)->cm.useGPU = use ; }
+
+// out[10]: Common->useGPU, L->useGPU, then the BLAS statistics of cholmod.h:966-986:
+// gpu gemm calls, gpu potrf calls, gpu gemm time, gpu potrf time, assemble time,
+// cpu (syrk + gemm + trsm + potrf) calls, cpu time of the same, reserved
+void ref_counters (void *hv, double *out)
+{
+    ref_ctx *h = hv ;
+    cholmod_common *cm = &h->cm ;
+    out [0] = cm->useGPU ;
+    out [1] = h->L ? h->L->useGPU : -1 ;
+    out [2] = (double) cm->cholmod_gpu_gemm_calls ;
+    out [3] = (double) cm->cholmod_gpu_potrf_calls ;
+    out [4] = cm->cholmod_gpu_gemm_time ;
+    out [5] = cm->cholmod_gpu_potrf_time ;
+    out [6] = cm->cholmod_assemble_time ;
+    out [7] = (double) (cm->cholmod_cpu_syrk_calls + cm->cholmod_cpu_gemm_calls + cm->cholmod_cpu_trsm_calls +
+                        cm->cholmod_cpu_potrf_calls) ;
+    out [8] = cm->cholmod_cpu_syrk_time + cm->cholmod_cpu_gemm_time + cm->cholmod_cpu_trsm_time +
+              cm->cholmod_cpu_potrf_time ;
+    out [9] = 0 ;
+}
+
+// free the factor now (the handle table must shrink with it)
+void ref_drop_factor (void *hv)
+{
+    ref_ctx *h = hv ;
+    cholmod_l_free_factor (&h->L, &h->cm) ;
+}
+
+// convert the factor IN PLACE to a packed monotonic simplicial one (cholmod_l_change_factor): it loses its
+// supernodal arrays, so a device image must go with them
+int ref_make_simplicial (void *hv, int to_ll)
+{
+    ref_ctx *h = hv ;
+    return cholmod_l_change_factor (h->L->xtype, to_ll, 0, 1, 1, h->L, &h->cm) ? 0 : -1 ;
+}
+
+#ifdef REF_HELPER_MI355
+int cholmod_mi355_live_handles (void) ;
+int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
+#else
+int ref_live_handles (void) { return -1 ; }
+#endif

@@ -30,40 +30,76 @@ def lib():
         # MKL's default threading layer is Intel OpenMP; CHOLMOD is built with libgomp
         os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
         L = C.CDLL(os.path.join(_HERE, "_ref", "libref_helper.so"), mode=C.RTLD_GLOBAL)
-        L.ref_new.restype = C.c_void_p
-        L.ref_free.argtypes = [C.c_void_p]
-        L.ref_nthreads.argtypes = [C.c_void_p]
-        L.ref_set_nthreads.argtypes = [C.c_void_p, C.c_int]
-        L.ref_load_matrix.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, f64p, C.c_int, C.c_int]
-        L.ref_read_matrix.argtypes = [C.c_void_p, C.c_char_p]
-        L.ref_load_matrix_rect.argtypes = [C.c_void_p, C.c_int64, C.c_int64, i64p, i64p, f64p, C.c_int]
-        L.ref_set_fset.argtypes = [C.c_void_p, C.c_int64]
-        L.ref_F_info.argtypes = [C.c_void_p, i64p]
-        L.ref_get_F.argtypes = [C.c_void_p, i64p, i64p, f64p]
-        L.ref_matrix_info.argtypes = [C.c_void_p, i64p]
-        L.ref_get_matrix.argtypes = [C.c_void_p, i64p, i64p, f64p]
-        L.ref_analyze.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-        L.ref_info.argtypes = [C.c_void_p, i64p, f64p]
-        L.ref_get_symbolic.argtypes = [C.c_void_p, i64p, i64p, i64p, i64p, i64p, i64p]
-        L.ref_permute.argtypes = [C.c_void_p]
-        L.ref_permute.restype = C.c_int64
-        L.ref_get_S.argtypes = [C.c_void_p, i64p, i64p, f64p]
-        L.ref_factorize.argtypes = [C.c_void_p, C.c_double, C.c_int]
-        L.ref_factorize_full.argtypes = [C.c_void_p, C.c_double]
-        L.ref_get_Lx.argtypes = [C.c_void_p, f64p]
-        L.ref_set_Lx.argtypes = [C.c_void_p, f64p, C.c_int64]
-        L.ref_super_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, f64p, C.c_int64]
-        L.ref_solve.argtypes = [C.c_void_p, C.c_int64, f64p, f64p]
+        _prototypes(L)
         _LIB = L
     return _LIB
+
+
+_LIB_DROPIN = None
+
+
+def dropin_available():
+    return available() and os.path.exists(os.path.join(_HERE, "_ref", "libref_helper_mi355.so"))
+
+
+def lib_dropin(engine_path):
+    """The reference CHOLMOD with the dispatch of INTEGRATION.md compiled in (oracle/build_ref_mi355.sh).  Its mi355_*
+    symbols are undefined: the engine library at `engine_path` is loaded first, globally.  The helper itself is loaded
+    RTLD_LOCAL | RTLD_DEEPBIND (and libcholmod_mi355.so is linked -Bsymbolic), so that its cholmod_l_* calls reach the
+    patched library even when the unchanged reference is loaded in the same process."""
+    global _LIB_DROPIN
+    if _LIB_DROPIN is None:
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        C.CDLL(engine_path, mode=C.RTLD_GLOBAL)
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_helper_mi355.so"), mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND | os.RTLD_NOW)
+        _prototypes(L)
+        L.engine_path = engine_path
+        _LIB_DROPIN = L
+    if _LIB_DROPIN.engine_path != engine_path:
+        raise RuntimeError("the drop-in build is already bound to " + _LIB_DROPIN.engine_path)
+    return _LIB_DROPIN
+
+
+def _prototypes(L):
+    L.ref_new.restype = C.c_void_p
+    L.ref_free.argtypes = [C.c_void_p]
+    L.ref_nthreads.argtypes = [C.c_void_p]
+    L.ref_set_nthreads.argtypes = [C.c_void_p, C.c_int]
+    L.ref_load_matrix.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, f64p, C.c_int, C.c_int]
+    L.ref_read_matrix.argtypes = [C.c_void_p, C.c_char_p]
+    L.ref_load_matrix_rect.argtypes = [C.c_void_p, C.c_int64, C.c_int64, i64p, i64p, f64p, C.c_int]
+    L.ref_set_fset.argtypes = [C.c_void_p, C.c_int64]
+    L.ref_F_info.argtypes = [C.c_void_p, i64p]
+    L.ref_get_F.argtypes = [C.c_void_p, i64p, i64p, f64p]
+    L.ref_matrix_info.argtypes = [C.c_void_p, i64p]
+    L.ref_get_matrix.argtypes = [C.c_void_p, i64p, i64p, f64p]
+    L.ref_analyze.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.ref_info.argtypes = [C.c_void_p, i64p, f64p]
+    L.ref_get_symbolic.argtypes = [C.c_void_p, i64p, i64p, i64p, i64p, i64p, i64p]
+    L.ref_permute.argtypes = [C.c_void_p]
+    L.ref_permute.restype = C.c_int64
+    L.ref_get_S.argtypes = [C.c_void_p, i64p, i64p, f64p]
+    L.ref_factorize.argtypes = [C.c_void_p, C.c_double, C.c_int]
+    L.ref_factorize_full.argtypes = [C.c_void_p, C.c_double]
+    L.ref_get_Lx.argtypes = [C.c_void_p, f64p]
+    L.ref_set_Lx.argtypes = [C.c_void_p, f64p, C.c_int64]
+    L.ref_super_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, f64p, C.c_int64]
+    L.ref_solve.argtypes = [C.c_void_p, C.c_int64, f64p, f64p]
+    L.ref_set_use_gpu.argtypes = [C.c_void_p, C.c_int]
+    L.ref_counters.argtypes = [C.c_void_p, f64p]
+    L.ref_drop_factor.argtypes = [C.c_void_p]
+    L.ref_make_simplicial.argtypes = [C.c_void_p, C.c_int]
 
 
 class RefCholmod:
     """One cholmod_common + matrix + factor of the reference library."""
 
-    def __init__(self, nthreads=None):
-        self.L = lib()
+    def __init__(self, nthreads=None, dropin=None):
+        """dropin: path of the engine library -> the build with the dispatch compiled in, Common->useGPU = 1"""
+        self.L = lib_dropin(dropin) if dropin else lib()
         self.h = self.L.ref_new()
+        if dropin:
+            self.L.ref_set_use_gpu(self.h, 1)
         if nthreads is not None:
             self.L.ref_set_nthreads(self.h, int(nthreads))
         self.n = 0
@@ -82,6 +118,26 @@ class RefCholmod:
 
     def nthreads(self):
         return self.L.ref_nthreads(self.h)
+
+    # ---- drop-in build ----
+    def set_use_gpu(self, use):
+        self.L.ref_set_use_gpu(self.h, int(use))
+
+    def counters(self):
+        out = np.zeros(10)
+        self.L.ref_counters(self.h, out)
+        keys = ("useGPU", "L_useGPU", "gpu_gemm_calls", "gpu_potrf_calls", "gpu_gemm_time", "gpu_potrf_time",
+                "assemble_time", "cpu_blas_calls", "cpu_blas_time")
+        return dict(zip(keys, out))
+
+    def live_handles(self):
+        return int(self.L.ref_live_handles())
+
+    def drop_factor(self):
+        self.L.ref_drop_factor(self.h)
+
+    def make_simplicial(self, to_ll=True):
+        return int(self.L.ref_make_simplicial(self.h, 1 if to_ll else 0))
 
     # ---- matrix ----
     def load(self, n, Ap, Ai, Ax, stype=-1):

@@ -1,0 +1,259 @@
+// cholmod_mi355.c -- the CHOLMOD side of the drop-in (include/cholmod_mi355.h): plain C, compiled INTO a CHOLMOD
+// build with -DCHOLMOD_HAS_MI355 (it needs cholmod.h), calling libmi355_cholmod.so through its C ABI.
+//
+// What it holds: the side table  cholmod_factor* -> mi355_factor*  (sizeof (cholmod_factor) stays what it is), the
+// selection logic of Common->useGPU / L->useGPU, and the translation of cholmod_sparse / cholmod_factor /
+// cholmod_dense fields into the plain arrays of the C ABI and of its results back into L->x, L->minor,
+// Common->status and the Common->cholmod_gpu_* counters.  Everything numeric happens behind the ABI.
+//
+// Reference interfaces mirrored (file:line under /root/reference):
+//   CHOLMOD/Supernodal/cholmod_super_symbolic.c:239-320   useGPU selection (env CHOLMOD_USE_GPU, probe, L->useGPU)
+//   CHOLMOD/Supernodal/cholmod_super_numeric.c:100-335     wrapper whose worker switch (:295-322) is taken over
+//   CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:233  "Common->useGPU == 1 && L->useGPU" gate
+//   CHOLMOD/Supernodal/cholmod_super_solve.c:52-139,153-240  lsolve / ltsolve wrappers
+//   CHOLMOD/Utility/t_cholmod_free_factor.c:22-90          where a factor loses its supernodal arrays
+//   CHOLMOD/GPU/t_cholmod_gpu.c:74-82                       error policy (report CHOLMOD_GPU_PROBLEM)
+//   CHOLMOD/Include/cholmod.h:966-986                       per-kernel time / call counters
+#include "cholmod_mi355.h"
+#include "mi355_cholmod.h"
+
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+// cholmod.h is the public header: these three live in cholmod_internal.h
+#ifndef TRUE
+#define TRUE 1
+#define FALSE 0
+#endif
+#ifndef EMPTY
+#define EMPTY (-1)
+#endif
+
+// ---- side table ------------------------------------------------------------------------------------------------
+// One entry per factor with a device image.  The signature guards against a recycled address: a factor whose
+// supernodal arrays were replaced (or whose xtype changed) never meets a stale handle.
+typedef struct
+{
+    const cholmod_factor *L ;
+    mi355_factor *h ;
+    const void *super, *s ;         // the arrays the handle was built from
+    size_t n, nsuper, ssize, xsize ;
+    int lx ;                        // MI355_REAL / MI355_COMPLEX
+} entry_t ;
+
+static entry_t *table = NULL ;
+static int table_len = 0, table_cap = 0 ;
+static pthread_mutex_t table_lock = PTHREAD_MUTEX_INITIALIZER ;
+
+static int find_locked (const cholmod_factor *L)
+{
+    for (int k = 0 ; k < table_len ; k++) if (table [k].L == L) return (k) ;
+    return (-1) ;
+}
+
+static int matches (const entry_t *e, const cholmod_factor *L, int lx)
+{
+    return (e->super == L->super && e->s == L->s && e->n == L->n && e->nsuper == L->nsuper &&
+            e->ssize == L->ssize && e->xsize == L->xsize && e->lx == lx) ;
+}
+
+// the handle of L if it is still the image of L's present structure, else NULL (a stale one is destroyed)
+static mi355_factor *handle_of (const cholmod_factor *L, int lx)
+{
+    mi355_factor *h = NULL, *stale = NULL ;
+    pthread_mutex_lock (&table_lock) ;
+    int k = find_locked (L) ;
+    if (k >= 0)
+    {
+        if (matches (&table [k], L, lx)) h = table [k].h ;
+        else
+        {
+            stale = table [k].h ;
+            table [k] = table [--table_len] ;
+        }
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    if (stale) mi355_factor_free (stale) ;
+    return (h) ;
+}
+
+static int remember_handle (const cholmod_factor *L, mi355_factor *h, int lx)
+{
+    pthread_mutex_lock (&table_lock) ;
+    if (table_len == table_cap)
+    {
+        int cap = table_cap ? 2 * table_cap : 8 ;
+        entry_t *t = realloc (table, (size_t) cap * sizeof (entry_t)) ;
+        if (!t) { pthread_mutex_unlock (&table_lock) ; return (0) ; }
+        table = t ; table_cap = cap ;
+    }
+    entry_t *e = &table [table_len++] ;
+    e->L = L ; e->h = h ; e->super = L->super ; e->s = L->s ;
+    e->n = L->n ; e->nsuper = L->nsuper ; e->ssize = L->ssize ; e->xsize = L->xsize ; e->lx = lx ;
+    pthread_mutex_unlock (&table_lock) ;
+    return (1) ;
+}
+
+void cholmod_mi355_forget (cholmod_factor *L)
+{
+    if (!L) return ;
+    mi355_factor *h = NULL ;
+    pthread_mutex_lock (&table_lock) ;
+    int k = find_locked (L) ;
+    if (k >= 0)
+    {
+        h = table [k].h ;
+        table [k] = table [--table_len] ;
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    if (h) mi355_factor_free (h) ;
+}
+
+int cholmod_mi355_live_handles (void)
+{
+    pthread_mutex_lock (&table_lock) ;
+    int k = table_len ;
+    pthread_mutex_unlock (&table_lock) ;
+    return (k) ;
+}
+
+// ---- selection ---------------------------------------------------------------------------------------------------
+void cholmod_mi355_select (cholmod_sparse *A, int for_whom, cholmod_factor *L, cholmod_common *Common)
+{
+    if (!(for_whom == CHOLMOD_ANALYZE_FOR_CHOLESKY && A->dtype == CHOLMOD_DOUBLE))
+    {
+        // as in the reference: the request is left as it is for other callers (SPQR) and single precision,
+        // which the numeric gate refuses anyway through L->useGPU == 0
+        L->useGPU = 0 ;
+        return ;
+    }
+    if (Common->useGPU == EMPTY)
+    {
+        const char *env = getenv ("CHOLMOD_USE_GPU") ;
+        Common->useGPU = (env && atoi (env) != 0) ? 1 : 0 ;
+    }
+    if (Common->useGPU == 1) Common->useGPU = (mi355_probe ( ) > 0) ? 1 : 0 ;
+    L->useGPU = Common->useGPU ;
+}
+
+// ---- numeric factorization -------------------------------------------------------------------------------------
+static void gpu_problem (cholmod_common *Common, const char *file, int line)
+{
+    cholmod_l_error (CHOLMOD_GPU_PROBLEM, file, line, mi355_last_error ( ), Common) ;
+}
+
+int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2], cholmod_factor *L,
+    cholmod_common *Common, int *ok)
+{
+    if (!(Common->useGPU == 1 && L->useGPU) || A->dtype != CHOLMOD_DOUBLE || L->dtype != CHOLMOD_DOUBLE ||
+        L->itype != CHOLMOD_LONG || A->stype > 0)
+    {
+        // the CPU worker is about to rewrite L->x: a device image of L would be stale afterwards
+        cholmod_mi355_forget (L) ;
+        return (FALSE) ;
+    }
+    // L is complex for a complex or zomplex A (cholmod_super_numeric.c:223-225)
+    const int lx = (A->xtype == CHOLMOD_REAL) ? MI355_REAL : MI355_COMPLEX ;
+    mi355_factor *h = handle_of (L, lx) ;
+    int rc = MI355_OK ;
+    if (h == NULL)
+    {
+        rc = mi355_factor_create (lx, (int64_t) L->n, (int64_t) L->nsuper, (const int64_t *) L->super,
+                (const int64_t *) L->pi, (const int64_t *) L->px, (const int64_t *) L->s,
+                (int64_t) L->ssize, (int64_t) L->xsize, /* device */ 0, &h) ;
+        if (rc == MI355_OK && !remember_handle (L, h, lx))
+        {
+            mi355_factor_free (h) ;
+            cholmod_l_error (CHOLMOD_OUT_OF_MEMORY, __FILE__, __LINE__, "out of memory", Common) ;
+            *ok = FALSE ;
+            return (TRUE) ;
+        }
+    }
+    int64_t minor = (int64_t) L->n ;
+    int status = MI355_STATUS_OK ;
+    if (rc == MI355_OK)
+    {
+#ifdef BLAS_TIMER
+        mi355_factor_set_profile (h, 1) ;
+#endif
+        const int64_t *Anz = A->packed ? NULL : (const int64_t *) A->nz ;
+        const int zomplex = (A->xtype == CHOLMOD_ZOMPLEX) ;
+        if (A->stype == 0)
+        {
+            // A*F + beta*I with F = A' or A(:,f)' (checked by the wrapper, cholmod_super_numeric.c:135-154)
+            rc = mi355_factor_set_matrix_unsym (h, (int64_t) A->ncol, (const int64_t *) A->p, (const int64_t *) A->i,
+                    Anz, (const double *) A->x, zomplex ? (const double *) A->z : NULL,
+                    (const int64_t *) F->p, (const int64_t *) F->i, F->packed ? NULL : (const int64_t *) F->nz,
+                    (const double *) F->x, zomplex ? (const double *) F->z : NULL) ;
+        }
+        else if (zomplex)
+        {
+            rc = mi355_factor_set_matrix_zomplex (h, (const int64_t *) A->p, (const int64_t *) A->i, Anz,
+                    (const double *) A->x, (const double *) A->z) ;
+        }
+        else
+        {
+            rc = mi355_factor_set_matrix (h, (const int64_t *) A->p, (const int64_t *) A->i, Anz,
+                    (const double *) A->x) ;
+        }
+        // only beta [0] is used (t_cholmod_super_numeric_worker.c:510-520)
+        if (rc == MI355_OK) rc = mi355_factor_numeric (h, beta [0], Common->quick_return_if_not_posdef, &minor, &status) ;
+        // L->x on the host is part of the contract: cholmod_solve, change_factor, rcond, factor_to_sparse read it
+        if (rc == MI355_OK) rc = mi355_factor_get_Lx (h, (double *) L->x) ;
+    }
+    if (rc != MI355_OK)
+    {
+        // same policy as CHOLMOD_HANDLE_CUDA_ERROR (t_cholmod_gpu.c:74-82): report, do not hide
+        if (rc == MI355_OUT_OF_MEMORY) cholmod_l_error (CHOLMOD_OUT_OF_MEMORY, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
+        else if (rc == MI355_TOO_LARGE) cholmod_l_error (CHOLMOD_TOO_LARGE, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
+        else gpu_problem (Common, __FILE__, __LINE__) ;
+        cholmod_mi355_forget (L) ;
+        *ok = FALSE ;
+        return (TRUE) ;
+    }
+    {
+        // BLAS statistics (cholmod.h:966-986, printed by cholmod_l_gpu_stats): here one GEMM launch is a batch of
+        // fused SYRK + GEMM + assembly (or TRSM) tasks, so they are all booked under GEMM; times only with BLAS_TIMER
+        double st [24] ;
+        if (mi355_factor_get_stats (h, st) == MI355_OK)
+        {
+            Common->cholmod_gpu_gemm_calls += (size_t) st [2] ;
+            Common->cholmod_gpu_potrf_calls += (size_t) st [4] ;
+#ifdef BLAS_TIMER
+            Common->cholmod_gpu_gemm_time += st [1] * 1e-3 ;
+            Common->cholmod_gpu_potrf_time += st [3] * 1e-3 ;
+            Common->cholmod_assemble_time += st [5] * 1e-3 ;
+#endif
+        }
+    }
+    L->minor = (size_t) minor ;
+    if (status == MI355_STATUS_NOT_POSDEF)
+    {
+        // a warning, not an error: super_numeric still returns TRUE (cholmod_super_numeric.c:37-41)
+        cholmod_l_error (CHOLMOD_NOT_POSDEF, __FILE__, __LINE__, "matrix not positive definite", Common) ;
+    }
+    *ok = TRUE ;
+    return (TRUE) ;
+}
+
+// ---- triangular solves -------------------------------------------------------------------------------------------
+int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, cholmod_common *Common, int *ok)
+{
+    if (L->dtype != CHOLMOD_DOUBLE || L->itype != CHOLMOD_LONG || X->dtype != CHOLMOD_DOUBLE) return (FALSE) ;
+    if (L->xtype != CHOLMOD_REAL && L->xtype != CHOLMOD_COMPLEX) return (FALSE) ;
+    if (L->minor < L->n) return (FALSE) ;           // not positive definite: the CPU worker sweeps what is in L->x
+    mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
+    if (h == NULL) return (FALSE) ;
+    const int rc = lower ? mi355_super_lsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d)
+                         : mi355_super_ltsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d) ;
+    if (rc != MI355_OK)
+    {
+        gpu_problem (Common, __FILE__, __LINE__) ;
+        *ok = FALSE ;
+        return (TRUE) ;
+    }
+    *ok = TRUE ;
+    return (TRUE) ;
+}

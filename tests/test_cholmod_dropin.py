@@ -1,0 +1,279 @@
+"""The drop-in boundary compiled for real: the reference CHOLMOD with the five insertions of INTEGRATION.md section 2
+(oracle/apply_dispatch.py applies them to copies, oracle/build_ref_mi355.sh compiles them together with OUR glue
+suitesparse_amd/csrc/cholmod_mi355.c into oracle/_ref/libcholmod_mi355.so) running
+
+        cholmod_l_analyze  ->  cholmod_l_factorize  ->  cholmod_l_solve
+
+through the public API, with the supernodal numeric factorization and the supernodal triangular solves taken over
+by the engine behind include/mi355_cholmod.h.  Pass criterion = the reference demo's own:  maxresid < 1e-7 with
+resid = ||A x - b||_inf / (||A||_inf ||x||_inf + ||b||_inf)   (CHOLMOD/Demo/cholmod_dl_demo.c:614-617,769-777), on the
+demo's matrices bcsstk01, bcsstk02 and c.tri (held as data in tests/golden/demo_*.npz), plus agreement of L->x,
+L->minor and Common->status with the unchanged reference's outputs stored in the same fixtures.
+
+Each case exists twice: [cpu] binds the patched CHOLMOD to the CPU build of the engine (tests/helpers/
+libmi355_cpuemu.so, test infrastructure), [gpu] (-m gpu) to the real suitesparse_amd/libmi355_cholmod.so.  One process
+binds one engine: the two sets run in the two separate pytest invocations (-m "not gpu" / -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, relerr
+
+CPUEMU = os.path.join(ROOT, "tests", "helpers", "libmi355_cpuemu.so")
+REAL = os.path.join(ROOT, "suitesparse_amd", "libmi355_cholmod.so")
+NOT_POSDEF = 1              # CHOLMOD_NOT_POSDEF (cholmod.h)
+
+BOTH = [pytest.param("cpu", id="cpu"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+
+
+def cases(cpu, gpu_only=()):
+    """(which, name) pairs: the thread-emulated CPU build of the engine is slow, so the larger fixtures run on the
+    GPU only"""
+    out = [pytest.param("cpu", n, id=f"{n}-cpu") for n in cpu]
+    out += [pytest.param("gpu", n, id=f"{n}-gpu", marks=pytest.mark.gpu) for n in list(cpu) + list(gpu_only)]
+    return out
+
+
+def _cholmod(which, **kw):
+    from oracle import refcholmod
+    path = REAL if which == "gpu" else CPUEMU
+    present = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_helper_mi355.so")) and os.path.exists(path)
+    if not present:
+        if which == "gpu" or os.path.isdir("/root/reference/CHOLMOD"):
+            pytest.fail("the drop-in build (oracle/build_ref_mi355.sh) or the engine library is missing: "
+                        "run __graft_entry__.build()")
+        pytest.skip("no reference here to build the patched CHOLMOD from")
+    try:
+        return refcholmod.RefCholmod(dropin=path, **kw)
+    except RuntimeError as e:               # the other engine is already bound in this process
+        pytest.skip(str(e))
+
+
+def _dense_A(g):
+    """the full Hermitian matrix of a golden fixture (stored as one triangle, stype +-1)"""
+    import scipy.sparse as sp
+    n = g["n"]
+    T = sp.csc_matrix((g["Ax"], g["Ai"], g["Ap"]), shape=(n, n)).toarray()
+    if g["stype"] < 0:
+        T = np.tril(T)
+    else:
+        T = np.triu(T)
+    return T + T.conj().T - np.diag(np.diag(T).real)
+
+
+def _demo_resid(A, X, B):
+    inf = lambda M: float(np.abs(M).sum(axis=1).max()) if M.size else 0.0
+    return inf(A @ X - B) / (inf(A) * inf(X) + inf(B))
+
+
+@pytest.mark.parametrize("which", BOTH)
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c"])
+def test_demo_chain_residual(which, name):
+    """analyze (the demo's default ordering strategy) -> factorize -> solve, forced supernodal, the demo's criterion"""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    inf = r.analyze(ordering=-1, supernodal=2)          # nmethods = 0: the default strategy of cholmod_analyze
+    assert inf["is_super"] == 1
+    c0 = r.counters()
+    assert c0["useGPU"] == 1 and c0["L_useGPU"] == 1, c0
+    assert r.factorize_full() == 0
+    c1 = r.counters()
+    assert c1["gpu_gemm_calls"] + c1["gpu_potrf_calls"] > 0 and c1["cpu_blas_calls"] == 0, c1
+    assert r.live_handles() >= 1
+    A = _dense_A(g)
+    rng = np.random.default_rng(1)
+    for B in (np.ones((n, 1)), rng.standard_normal((n, 4))):
+        if g["xtype"] == 2:
+            B = B + 1j * rng.standard_normal(B.shape)
+        X = r.solve(B)
+        assert _demo_resid(A, X, B) < 1e-7
+    r.close()
+
+
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "elast27_4_metis", "tcov_z30lo",
+                                               "tcov_c30up"], ["lap3d_8_metis", "helm3d_6_metis", "lap2d_16_metis"]))
+def test_same_factor_as_unchanged_reference(which, name):
+    """on the fixture's permutation the patched build must hand back the SAME cholmod_factor: structure bit-exact,
+    L->x within 1e-10 of what the unchanged reference produced (fixture), solution of cholmod_l_solve likewise"""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    s = r.symbolic()
+    for k in ("Super", "Lpi", "Lpx", "Ls", "Perm"):
+        assert np.array_equal(s[k], g[k]), k
+    assert r.factorize_full(beta=g["beta"]) == g["status"] == 0
+    assert r.info()["minor"] == g["minor"] == n
+    assert relerr(r.Lx(), g["Lx"]) < 1e-10
+    # cholmod_l_solve: P, the two supernodal sweeps on the device, P'
+    X = r.solve(g["B"])
+    A = _dense_A(g) + g["beta"] * np.eye(n)
+    want = np.linalg.solve(A, g["B"])
+    assert relerr(X, want) < 1e-9
+    assert _demo_resid(A, X, g["B"]) < 1e-12
+    # the two sweeps one at a time (cholmod_l_super_lsolve / _ltsolve), against the fixture's Y and Z
+    Y = r.super_solve(g["B"], lower=True)
+    assert relerr(Y, g["Y"]) < 1e-10
+    Z = r.super_solve(Y, lower=False)
+    assert relerr(Z, g["Z"]) < 1e-10
+    r.close()
+
+
+@pytest.mark.parametrize("which,name", cases(["tcov_c30lo_singular", "elast27_4_npd100"],
+                                             ["lap3d_8_npd200", "lap2d_16_npd0"]))
+def test_not_posdef_through_the_api(which, name):
+    """a warning, not an error: Common->status = CHOLMOD_NOT_POSDEF, L->minor = the failing column, the columns
+    before it as the reference leaves them, the rest zero (t_cholmod_super_numeric_worker.c:1084-1146)"""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full(beta=g["beta"]) == NOT_POSDEF == g["status"]
+    assert r.info()["minor"] == g["minor"] < n
+    Lx = r.Lx()
+    assert np.array_equal(Lx == 0, g["Lx"] == 0)
+    assert relerr(Lx, g["Lx"]) < 1e-10
+    # cholmod_l_solve on such a factor stays on the CPU worker (it sweeps what is in L->x) and must not fail
+    X = r.solve(g["B"])
+    assert X.shape == g["B"].shape
+    r.close()
+
+
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk02"], ["lap3d_8_metis"]))
+def test_refactorize_reuses_the_device_image_and_teardown(which, name):
+    """second cholmod_l_factorize on the same L: same handle, new values; cholmod_l_free_factor and
+    cholmod_l_change_factor (supernodal -> simplicial) destroy the device image; the converted factor still solves"""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    base = r.live_handles()
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.live_handles() == base                 # analysis reserves nothing on the device
+    assert r.factorize_full() == 0
+    assert r.live_handles() == base + 1
+    L1 = r.Lx()
+    shift = 0.5 * float(np.abs(g["Ax"]).max())
+    assert r.factorize_full(beta=shift) == 0        # A + shift I
+    assert r.live_handles() == base + 1
+    A = _dense_A(g) + shift * np.eye(n)
+    X = r.solve(g["B"])
+    assert _demo_resid(A, X, g["B"]) < 1e-12
+    assert relerr(r.Lx(), L1) > 1e-3
+    assert r.factorize_full() == 0
+    assert relerr(r.Lx(), g["Lx"]) < 1e-10
+    # supernodal -> simplicial LL': the device image goes, the values stay, the simplicial solve works
+    assert r.make_simplicial(True) == 0
+    assert r.live_handles() == base
+    assert r.info()["is_super"] == 0
+    X = r.solve(g["B"])
+    assert _demo_resid(_dense_A(g), X, g["B"]) < 1e-12
+    # a new factor, freed while it has an image
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    assert r.live_handles() == base + 1
+    r.drop_factor()
+    assert r.live_handles() == base
+    r.close()
+
+
+@pytest.mark.parametrize("which", BOTH)
+def test_use_gpu_off_runs_the_cpu_workers(which):
+    """Common->useGPU = 0: the hooks step aside, the unchanged CPU workers run, no device image appears"""
+    g = load_golden("lap3d_8_metis")
+    r = _cholmod(which)
+    base = r.live_handles()
+    r.set_use_gpu(0)
+    r.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    c = r.counters()
+    assert c["L_useGPU"] == 0 and c["gpu_gemm_calls"] == 0 and c["gpu_potrf_calls"] == 0, c
+    assert r.live_handles() == base
+    assert relerr(r.Lx(), g["Lx"]) < 1e-12
+    assert relerr(r.solve(g["B"]), np.linalg.solve(_dense_A(g), g["B"])) < 1e-9
+    r.close()
+
+
+@pytest.mark.parametrize("which", BOTH)
+def test_cpu_refactorization_drops_a_stale_image(which):
+    """factorize on the device, then switch Common->useGPU off and factorize again: the CPU worker rewrites L->x, so
+    the device image must go, and the following solve must use the NEW values"""
+    g = load_golden("demo_bcsstk01")
+    n = g["n"]
+    r = _cholmod(which)
+    base = r.live_handles()
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    assert r.live_handles() == base + 1
+    r.set_use_gpu(0)
+    shift = float(np.abs(g["Ax"]).max())
+    assert r.factorize_full(beta=shift) == 0
+    assert r.live_handles() == base
+    A = _dense_A(g) + shift * np.eye(n)
+    assert _demo_resid(A, r.solve(g["B"]), g["B"]) < 1e-12
+    r.close()
+
+
+@pytest.mark.parametrize("which", BOTH)
+@pytest.mark.parametrize("name", ["tcov_5by50", "tcov_5by50_beta", "tcov_c10", "lp_afiro"])
+def test_unsymmetric_chain(which, name):
+    """stype == 0: cholmod_l_factorize forms F = A(p,:)' and hands (A, F) to super_numeric, which factorizes
+    A F + beta I (cholmod_factorize.c:201-250); here the hook passes both to mi355_factor_set_matrix_unsym"""
+    import test_unsym as tu
+    g = tu.load_unsym(name)
+    r = _cholmod(which)
+    r.load_rect(g["n"], g["ncol"], g["Ap"], g["Ai"], g["Ax"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    s = r.symbolic()
+    for k in ("Super", "Lpi", "Lpx", "Ls"):
+        assert np.array_equal(s[k], g[k]), k
+    assert r.factorize_full(beta=g["beta"]) == g["status"]
+    assert r.info()["minor"] == g["minor"]
+    c = r.counters()
+    assert c["L_useGPU"] == 1 and c["cpu_blas_calls"] == 0, c
+    assert np.array_equal(r.Lx() == 0, g["Lx"] == 0)
+    assert relerr(r.Lx(), g["Lx"]) < 1e-10
+    r.close()
+
+
+@pytest.mark.parametrize("which", BOTH)
+def test_blas_statistics_are_filled(which):
+    """Common->cholmod_gpu_*_calls/_time (cholmod.h:966-986; cholmod_l_gpu_stats prints them,
+    CHOLMOD/Check/cholmod_check.c:608-672): the patched build is compiled with BLAS_TIMER as the reference's GPU
+    build is, so both calls and times must move with every factorization"""
+    g = load_golden("demo_bcsstk02")
+    r = _cholmod(which)
+    r.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    c1 = r.counters()
+    assert c1["gpu_gemm_calls"] > 0 and c1["gpu_potrf_calls"] > 0, c1
+    assert c1["gpu_gemm_time"] > 0 and c1["gpu_potrf_time"] > 0, c1
+    assert r.factorize_full() == 0
+    c2 = r.counters()
+    assert c2["gpu_gemm_calls"] == 2 * c1["gpu_gemm_calls"] and c2["gpu_potrf_calls"] == 2 * c1["gpu_potrf_calls"]
+    assert c2["gpu_gemm_time"] > c1["gpu_gemm_time"]
+    r.close()
+
+
+def test_integration_md_lists_what_is_compiled():
+    """every line oracle/apply_dispatch.py inserts into the reference's files appears verbatim in INTEGRATION.md"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("apply_dispatch", os.path.join(ROOT, "oracle", "apply_dispatch.py"))
+    ad = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ad)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for ln in ad.INCLUDE:
+        assert ln in doc, ln
+    for rel, edits in ad.EDITS.items():
+        assert rel in doc, rel
+        for _, _, ins in edits:
+            for ln in ins or ():
+                assert ln.strip() in doc, (rel, ln)
