@@ -66,3 +66,25 @@ def test_product_knows_nothing_of_the_cpu_emulation():
     assert "cpuemu" not in inspect.getsource(ge.smoke)
     from suitesparse_amd import engine
     assert engine.LIB_PATH.endswith(os.path.join("suitesparse_amd", "libmi355_cholmod.so"))
+
+
+def test_cholmod_side_glue_exports_its_header():
+    """include/cholmod_mi355.h (the CHOLMOD side of the drop-in) against the patched build of the reference: every
+    declared hook is defined there, and every mi355_* symbol that build leaves undefined is declared in
+    include/mi355_cholmod.h (so it binds to the engine and to nothing else)"""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "libcholmod_mi355.so")
+    if not os.path.exists(so):
+        if os.path.isdir("/root/reference/CHOLMOD"):
+            pytest.fail("oracle/_ref/libcholmod_mi355.so missing: run __graft_entry__.build()")
+        pytest.skip("no patched reference build here")
+    txt = open(os.path.join(ROOT, "include", "cholmod_mi355.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(cholmod_mi355_[a-z_]+)\s*\(", txt)))
+    assert len(hooks) == 5
+    nm = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout.splitlines()
+    defined = {ln.split()[-1] for ln in nm if " T " in ln}
+    undefined = {ln.split()[-1] for ln in nm if " U " in ln and ln.split()[-1].startswith("mi355_")}
+    for h in hooks:
+        assert h in defined, h
+    assert undefined and undefined <= set(declared_symbols()), undefined - set(declared_symbols())
