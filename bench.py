@@ -46,23 +46,38 @@ def make_problem(kind, grid):
     raise ValueError(kind)
 
 
-def analyze(p):
+def metis_perm(p):
+    """the permutation the REFERENCE's analysis picks with METIS (cholmod_l_analyze, CHOLMOD_METIS,
+    CHOLMOD/Cholesky/cholmod_analyze.c:629-684) -- input data for --ordering metis, computed by oracle/_ref before
+    anything is timed"""
+    from oracle import refcholmod
+    if not refcholmod.available():
+        raise SystemExit("--ordering metis needs oracle/_ref (the reference's METIS)")
+    r = refcholmod.RefCholmod()
+    r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+    r.analyze(ordering="metis")
+    perm = r.symbolic()["Perm"]
+    r.close()
+    return perm
+
+
+def analyze(p, ordering="nd"):
     from suitesparse_amd import symbolic
     t = time.time()
-    perm = symbolic.nd_grid_order(p["shape"], p["dof"])
+    perm = metis_perm(p) if ordering == "metis" else symbolic.nd_grid_order(p["shape"], p["dof"])
     sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], perm)
     Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
     return sym, (Sp, Si, Sx), time.time() - t
 
 
-def cpu_baseline(kind, grid):
+def cpu_baseline(kind, grid, ordering="nd"):
     """reference CPU supernodal numeric (cholmod_l_super_numeric, host BLAS) on a bounded sample"""
     try:
         from oracle import refcholmod
         if not refcholmod.available():
             raise RuntimeError("oracle/_ref not present")
         p, name = make_problem(kind, grid)
-        sym, (Sp, Si, Sx), _ = analyze(p)
+        sym, (Sp, Si, Sx), _ = analyze(p, ordering)
         r = refcholmod.RefCholmod()
         r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
         inf = r.analyze(perm=sym["Perm"])           # CHOLMOD_GIVEN: same ordering as the GPU leg
@@ -83,9 +98,18 @@ def cpu_baseline(kind, grid):
             r.super_solve(y, lower=False)
             dt = time.time() - t0
             tsolve = dt if tsolve is None else min(tsolve, dt)
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except AttributeError:
+            affinity = os.cpu_count()
         return {"value": round(inf["fl"] / best * 1e-9, 2), "unit": "GFLOP/s", "cores": int(r.nthreads()),
                 "kind": "reference", "solve_ms_nrhs1": round(tsolve * 1e3, 2),
-                "sample": f"{name}, same nested-dissection ordering, fl={inf['fl']:.4g}, "
+                "threads": {"omp_get_max_threads": int(r.nthreads()), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                            "MKL_NUM_THREADS": os.environ.get("MKL_NUM_THREADS"),
+                            "MKL_THREADING_LAYER": os.environ.get("MKL_THREADING_LAYER"),
+                            "cpus_in_affinity_mask": affinity, "os_cpu_count": os.cpu_count()},
+                "L_ordering": inf["ordering_name"], "fl": inf["fl"], "factor_s": round(best, 3),
+                "sample": f"{name}, same {'METIS' if ordering == 'metis' else 'nested-dissection'} ordering, fl={inf['fl']:.4g}, "
                           f"reference cholmod_l_super_numeric + MKL, best of 2 = {best:.3f} s; "
                           f"cholmod_l_super_lsolve + _ltsolve, nrhs 1, best of 2 = {tsolve * 1e3:.1f} ms"}
     except Exception as e:      # noqa: BLE001
@@ -104,6 +128,9 @@ def main():
     ap.add_argument("--solve", action="store_true", help="also time the supernodal solve")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--tune", default="", help="experiments: key=value,... (keys of mi355_set_tuning, include/mi355_cholmod.h)")
+    ap.add_argument("--ordering", default="nd", choices=["nd", "metis"],
+                    help="nd: the engine's geometric nested dissection; metis: the permutation the reference's own "
+                         "analysis picks (computed by oracle/_ref before the timed region, passed in as data)")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +154,7 @@ def main():
     default_grid = {"lap3d": 150, "lap2d": 2000, "elast": 80, "helm": 100}[args.problem]
     grid = args.grid or default_grid
     p, name = make_problem(args.problem, grid)
-    sym, (Sp, Si, Sx), t_analyze = analyze(p)
+    sym, (Sp, Si, Sx), t_analyze = analyze(p, args.ordering)
 
     t0 = time.time()
     cplx = np.iscomplexobj(p["Ax"])
@@ -136,8 +163,28 @@ def main():
     t_setup = time.time() - t0
     if world > 1:
         from suitesparse_amd import multigpu
-        runner = multigpu.PartitionedFactor(L, sym, rank, world)
-        step = runner.numeric
+        # the whole N > 1 driver runs behind the C ABI (mi355_factor_numeric_multi) on an RCCL communicator of the
+        # engine's own; MI355_MULTI=python keeps the older torch.distributed driver of multigpu.py.  Whether the
+        # communicator could be created is agreed on by all ranks, so that they take the same path.
+        comm = None
+        if os.environ.get("MI355_MULTI", "c") != "python" and dist.get_backend() == "nccl":
+            try:
+                comm = engine.Comm.from_torch_distributed(local_rank)
+            except Exception as e:      # noqa: BLE001
+                print(f"[rank {rank}] RCCL communicator of the engine not created: {e}", file=sys.stderr, flush=True)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm = None
+        if comm is not None:
+            runner = multigpu.PartitionedFactor(L, sym, rank, world, comm=comm)
+        else:
+            runner = multigpu.PartitionedFactor(L, sym, rank, world, allreduce=multigpu.PartitionedFactor._dist_allreduce,
+                                                reduce=multigpu.PartitionedFactor._dist_reduce)
+
+        def step():
+            st = runner.numeric()
+            assert st == 0, f"factorization failed: status {st}"
     else:
         def step():
             st = L.numeric()
@@ -207,13 +254,16 @@ def main():
         "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": name + ", geometric nested dissection, supernodal LL' (int64, double)",
+        "config": {"workload": name + (", the reference's METIS ordering" if args.ordering == "metis"
+                                       else ", geometric nested dissection") + ", supernodal LL' (int64, double)",
                    "n": p["n"], "fl": sym["fl"], "lnz": sym["lnz"], "nsuper": sym["nsuper"],
                    "xsize": sym["xsize"], "levels": int(st["nlevels"]), "update_pairs": int(st["npairs"]),
                    "exec_flops": {"update": st["flops_update"], "panel": st["flops_panel"]},
                    "parallelism": "1 GPU" if world == 1 else
                    f"subtree-to-GPU x{world} + " + ("owner-computes top (1024-column blocks, broadcasts)"
-                                                    if runner.dist else "replicated top"),
+                                                    if runner.dist else "replicated top") +
+                   (", C driver on the engine's RCCL communicator" if runner.comm is not None
+                    else ", torch.distributed driver"),
                    "analyze_s": round(t_analyze, 2), "setup_s": round(t_setup, 2),
                    "frac_fp64_mfma_peak": round(gflops * 1e-3 * (4 if cplx else 1)
                                                 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
@@ -273,8 +323,9 @@ def main():
                 out["config"]["mfma_f64_measured_tflops"] = round(engine.mfma_f64_rate(local_rank), 2)
             except Exception:   # noqa: BLE001
                 pass
-            cg = args.cpu_grid or {"lap3d": 72, "lap2d": 1200, "elast": 30, "helm": 48}[args.problem]
-            out["cpu_baseline"] = cpu_baseline(args.problem, min(cg, grid))
+            # bounded sample, ~10-40 s of host work: lap3d 100^3 is fl 6.3e12 (8 GB of host factor)
+            cg = args.cpu_grid or {"lap3d": 100, "lap2d": 2000, "elast": 40, "helm": 56}[args.problem]
+            out["cpu_baseline"] = cpu_baseline(args.problem, min(cg, grid), args.ordering)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only"}

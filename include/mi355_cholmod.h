@@ -181,6 +181,73 @@ double *mi355_factor_device_Dinv(mi355_factor *handle);
 int mi355_super_solve_phase_dev(mi355_factor *handle, int part, int lower, int64_t nrhs, double *X, int64_t d);
 int mi355_solve_keep_rows_dev(mi355_factor *handle, int64_t nrhs, double *X, int64_t d);
 
+/* ---- more than one GPU behind one call (no counterpart in the reference: one device, cholmod_gpu.c:138-142).
+ *      One process per GPU; every rank creates its handle on the SAME symbolic factor, stages the SAME matrix and makes
+ *      the same calls.  What suitesparse_amd/multigpu.py used to drive from Python lives here, so that a C caller
+ *      (CHOLMOD is one) can use N > 1. */
+
+/* Whole etree subtrees -> ranks.  owner[nsuper] receives the rank of the subtree each supernode lies in, or -1 for
+ * the shared top (the ancestors of the cut).  The heaviest subtree is split until it weighs at most
+ * total / (2 world) and at least min_subtrees_per_rank * world subtrees exist; they go to the least loaded rank,
+ * heaviest first (weights: nscol^3/3 + nsrow2 nscol^2 + nscol nsrow2^2 flops per supernode).  Pure host work, no
+ * device needed.  The supernodes of a subtree need not be contiguous (a factor analysed without postordering is
+ * fine); a supernode whose parent does not come after it is rejected (MI355_INVALID).
+ * stats (may be NULL): [0] flops of the top, [1] total, [2 + r] load of rank r. */
+int mi355_partition(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Ls,
+                    int world, int min_subtrees_per_rank, int32_t *owner, double *stats);
+
+/* mi355_partition on the handle's symbolic factor + mi355_factor_set_partition with this rank's masks (rank 0
+ * assembles the top's entries of A) + (distribute_top != 0) mi355_factor_set_top_distribution + the order of the
+ * per-block reductions.  distribute_top == 0: the top is summed once over the ranks and factorized by every rank. */
+int mi355_factor_partition(mi355_factor *handle, int rank, int world, int min_subtrees_per_rank,
+                           int distribute_top);
+
+/* what mi355_factor_partition decided: owner[nsuper] (may be NULL) and counts[8] (may be NULL): world, rank, blocks of
+ * the distributed top (= broadcasts = reductions), merged top ranges, reductions planned, own-subtree steps enqueued
+ * before the first / before the last reduction may start, own-subtree steps in all. */
+int mi355_factor_partition_info(mi355_factor *handle, int32_t *owner, int64_t *counts);
+
+/* The collectives.  Either RCCL over xGMI -- stream-ordered: the engine's compute stream and the communicator's own
+ * stream order each other with events, the host does not wait inside a factorization; librccl is bound at run time
+ * (the copy the process already holds, else the system's), the engine has no link-time dependency on it --
+ *   mi355_rccl_unique_id(id)               on one rank: 128 bytes (ncclGetUniqueId) for the caller to hand to the others
+ *   mi355_comm_create_rccl(id, rank, world, device, &c)     ncclCommInitRank on `device`
+ *   mi355_comm_adopt_rccl(ncclComm, rank, world, device, &c)   an ncclComm_t the caller already has (not destroyed)
+ * or blocking callbacks of the caller's (MPI, a test harness): buffers are DEVICE pointers of the calling rank, counts
+ * are in doubles, the engine has finished its own work on a buffer before it calls and uses it after the callback
+ * returns; every rank calls the same callbacks in the same order; 0 = success. */
+typedef struct mi355_comm_s mi355_comm;
+typedef struct {
+    int rank, world;
+    void *ctx;
+    int (*reduce_sum)(void *ctx, double *dev, int64_t count, int root);      /* sum over the ranks into rank root */
+    int (*bcast)(void *ctx, double *dev, int64_t count, int root);
+    int (*allreduce_sum)(void *ctx, double *dev, int64_t count);
+    int (*allreduce_min_i64)(void *ctx, int64_t *host_value);                 /* one value, on the host */
+} mi355_transport;
+int mi355_comm_create(const mi355_transport *t, mi355_comm **comm);
+int mi355_rccl_unique_id(void *id128);
+int mi355_comm_create_rccl(const void *id128, int rank, int world, int device, mi355_comm **comm);
+int mi355_comm_adopt_rccl(void *nccl_comm, int rank, int world, int device, mi355_comm **comm);
+int mi355_comm_free(mi355_comm *comm);
+
+/* mi355_factor_numeric on N ranks (after mi355_factor_partition and a set_matrix call on every rank):
+ *   own subtrees; each block of the top panels is summed into its owner (reduce) as soon as this rank's last
+ *   contribution to it is enqueued, beside the remaining subtree work; the top, owner-computes, every finished block
+ *   broadcast before it is read; the block inverses of the top summed over the ranks (for the solves); ONE agreement
+ *   on the status.  *minor / *status as mi355_factor_numeric, identical on every rank.  Not positive definite: every
+ *   rank replays the reference's protocol on its own with the undistributed schedule (then the WHOLE truncated factor
+ *   is resident on every rank, as after mi355_factor_numeric).  After success each rank holds its subtrees' and the
+ *   top's columns of L; mi355_super_solve_multi_dev solves with them.  world == 1: mi355_factor_numeric. */
+int mi355_factor_numeric_multi(mi355_factor *handle, mi355_comm *comm, double beta_re,
+                               int quick_return_if_not_posdef, int64_t *minor, int *status);
+
+/* L x = b (lower != 0) or L^H x = b on the partitioned factor: X (device, n x nrhs entries, ld d) holds the same
+ * right-hand sides on every rank on entry and the same solution on every rank on return; one sum of X over the ranks
+ * per sweep is the only exchange. */
+int mi355_super_solve_multi_dev(mi355_factor *handle, mi355_comm *comm, int lower, int64_t nrhs, double *X_dev,
+                                int64_t d);
+
 /* ---- supernodal triangular solves: replace cholmod_l_super_lsolve / _ltsolve
  *      (CHOLMOD/Supernodal/cholmod_super_solve.c:52,153; workers
  *      t_cholmod_super_solve_worker.c:20-303,309-580).  X is n x nrhs, column-major,

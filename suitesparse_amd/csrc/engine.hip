@@ -112,6 +112,12 @@ struct mi355_factor_s {
     DeviceSchedule *part_dist = nullptr;   // the top, owner-computes over the ranks (mi355_factor_set_top_distribution)
     std::vector<int8_t> top_mask_host;
     DevBuf<int8_t> asm_mask;
+    // mi355_factor_partition (multi.hip.hpp): who owns what, and the order of the reductions of the top's blocks
+    int part_world = 0, part_rank = 0;      // part_world == 0: not called (or undone by a direct set_partition)
+    std::vector<int32_t> part_owner;        // rank of each supernode's subtree, -1 = top
+    struct ReduceItem { int64_t k; int64_t ready_step; };   // block k of the plan; own-subtree steps enqueued before it
+    std::vector<ReduceItem> reduce_plan;
+    std::vector<std::pair<int64_t, int64_t>> top_ranges;    // Lx ranges of the top supernodes, adjacent ones merged
     // staged matrix
     DevBuf<int64_t> Ap, Ai, Anz;
     DevBuf<double> Ax;
@@ -842,6 +848,8 @@ int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const 
     delete F->part_local; F->part_local = nullptr;
     delete F->part_top; F->part_top = nullptr;
     delete F->part_dist; F->part_dist = nullptr;
+    F->part_world = 0;
+    F->reduce_plan.clear();
     F->top_mask_host.assign(top_mask, top_mask + S.nsuper);
     F->part_local = new DeviceSchedule;
     F->part_top = new DeviceSchedule;
@@ -1653,3 +1661,5 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
 }
 
 }  // extern "C"
+
+#include "multi.hip.hpp"

@@ -39,7 +39,21 @@ EXPORTS = [
     "mi355_factor_set_top_distribution", "mi355_factor_top_plan", "mi355_factor_top_run", "mi355_factor_device_Dinv",
     "mi355_debug_gemm_rate", "mi355_set_tuning", "mi355_factor_set_matrix_zomplex",
     "mi355_factor_set_matrix_unsym", "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
+    "mi355_partition", "mi355_factor_partition", "mi355_factor_partition_info", "mi355_comm_create", "mi355_rccl_unique_id",
+    "mi355_comm_create_rccl", "mi355_comm_adopt_rccl", "mi355_comm_free", "mi355_factor_numeric_multi",
+    "mi355_super_solve_multi_dev",
 ]
+
+# mi355_transport (include/mi355_cholmod.h): blocking collectives of the caller's
+_RED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+_BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+_AMIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64))
+
+
+class _Transport(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("ctx", C.c_void_p), ("reduce_sum", _RED), ("bcast", _BC),
+                ("allreduce_sum", _AR), ("allreduce_min_i64", _AMIN)]
 
 _LIB = None
 
@@ -99,6 +113,18 @@ def lib():
         L.mi355_factor_top_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mi355_factor_device_Dinv.argtypes = [C.c_void_p]
         L.mi355_factor_device_Dinv.restype = C.c_void_p
+        _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.mi355_partition.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _i64p, C.c_int, C.c_int, _i32p, C.c_void_p]
+        L.mi355_factor_partition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mi355_factor_partition_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_comm_create.argtypes = [C.POINTER(_Transport), C.POINTER(C.c_void_p)]
+        L.mi355_rccl_unique_id.argtypes = [C.c_char_p]
+        L.mi355_comm_create_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi355_comm_adopt_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi355_comm_free.argtypes = [C.c_void_p]
+        L.mi355_factor_numeric_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int)]
+        L.mi355_super_solve_multi_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -136,6 +162,88 @@ def gemm_rate(kernel, M, N, K, iters=10, device=0):
 
 def set_tuning(key, value):
     _check(lib().mi355_set_tuning(int(key), int(value)))
+
+
+def partition(sym, world, min_subtrees_per_rank=2):
+    """mi355_partition: (owner[nsuper] int32 (-1 = top), top flops, total flops, per-rank loads).  Host work only."""
+    ns = int(sym["nsuper"])
+
+    def arr(a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        return a if a.size else np.zeros(1, dtype=np.int64)
+    owner = np.zeros(max(ns, 1), dtype=np.int32)
+    stats = np.zeros(2 + int(world))
+    _check(lib().mi355_partition(int(sym["n"]), ns, arr(sym["Super"]), arr(sym["Lpi"]), arr(sym["Ls"]), int(world),
+                                 int(min_subtrees_per_rank), owner, stats.ctypes.data_as(C.c_void_p)))
+    return owner[:ns], float(stats[0]), float(stats[1]), stats[2:].tolist()
+
+
+class Comm:
+    """mi355_comm: the collectives of mi355_factor_numeric_multi / mi355_super_solve_multi_dev."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self._h, self.rank, self.world, self._keep = handle, rank, world, keep
+
+    @classmethod
+    def custom(cls, rank, world, reduce_sum, bcast, allreduce_sum, allreduce_min):
+        """blocking collectives of the caller's: reduce_sum(ptr, count, root), bcast(ptr, count, root),
+        allreduce_sum(ptr, count) on DEVICE pointers (counts in doubles), allreduce_min(value) -> value on the host"""
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:          # an exception cannot cross the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            return run
+
+        def amin(_, p):
+            p[0] = int(allreduce_min(int(p[0])))
+        t = _Transport(int(rank), int(world), None,
+                       _RED(guard(lambda _, p, n, r: reduce_sum(p, n, r))), _BC(guard(lambda _, p, n, r: bcast(p, n, r))),
+                       _AR(guard(lambda _, p, n: allreduce_sum(p, n))), _AMIN(guard(amin)))
+        h = C.c_void_p()
+        _check(lib().mi355_comm_create(C.byref(t), C.byref(h)))
+        return cls(h, int(rank), int(world), keep=t)
+
+    @classmethod
+    def rccl(cls, rank, world, device, exchange):
+        """RCCL communicator of its own: exchange(id_or_None) hands rank 0's 128-byte id to every rank (any side
+        channel: MPI_Bcast, a file, torch.distributed) and returns it"""
+        idb = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _check(lib().mi355_rccl_unique_id(buf))
+            idb = buf.raw
+        idb = exchange(idb)
+        h = C.c_void_p()
+        _check(lib().mi355_comm_create_rccl(idb, int(rank), int(world), int(device), C.byref(h)))
+        return cls(h, int(rank), int(world))
+
+    @classmethod
+    def from_torch_distributed(cls, device):
+        """the ranks of the initialised torch.distributed process group (backend nccl = RCCL): the id travels through
+        it, the communicator is the engine's own"""
+        import torch.distributed as dist
+
+        def exchange(idb):
+            box = [idb]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls.rccl(dist.get_rank(), dist.get_world_size(), device, exchange)
+
+    def close(self):
+        if self._h:
+            lib().mi355_comm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
@@ -417,6 +525,32 @@ class SupernodalFactor:
                                           "version": 2}
             out.append(torch.as_tensor(v, device="cuda"))
         return out
+
+    # ---- more than one GPU behind the C ABI ----
+    def partition(self, rank, world, min_subtrees_per_rank=2, distribute_top=True):
+        """mi355_factor_partition; returns (owner[nsuper], counts dict)"""
+        _check(lib().mi355_factor_partition(self._h, int(rank), int(world), int(min_subtrees_per_rank),
+                                            int(bool(distribute_top))))
+        return self.partition_info()
+
+    def partition_info(self):
+        owner = np.zeros(max(self.nsuper, 1), dtype=np.int32)
+        cnt = np.zeros(8, dtype=np.int64)
+        _check(lib().mi355_factor_partition_info(self._h, owner.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        keys = ("world", "rank", "top_blocks", "top_ranges", "reductions", "steps_before_first_reduce",
+                "steps_before_last_reduce", "own_steps")
+        return owner[:self.nsuper], dict(zip(keys, cnt.tolist()))
+
+    def numeric_multi(self, comm, beta=0.0, quick_return_if_not_posdef=False):
+        minor, status = C.c_int64(0), C.c_int(0)
+        _check(lib().mi355_factor_numeric_multi(self._h, comm._h, float(beta), int(bool(quick_return_if_not_posdef)),
+                                                C.byref(minor), C.byref(status)))
+        self.minor, self.status = int(minor.value), int(status.value)
+        return self.status
+
+    def solve_multi_dev(self, comm, lower, X_ptr, nrhs, d):
+        _check(lib().mi355_super_solve_multi_dev(self._h, comm._h, int(bool(lower)), int(nrhs), C.c_void_p(int(X_ptr)),
+                                                 int(d)))
 
     # ---- instrumentation ----
     def set_profile(self, on=True):

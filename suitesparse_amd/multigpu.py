@@ -49,55 +49,22 @@ def supernode_tree(sym):
 
 
 def partition(sym, world, min_subtrees_per_rank=2):
-    """Returns dict(owner[nsuper] (-1 = top), top_ranges [(lo,hi) Lx offsets], stats)."""
-    ns = int(sym["nsuper"])
-    parent, work = supernode_tree(sym)
-    sub = work.copy()
-    first = np.arange(ns, dtype=np.int64)            # first (lowest) supernode of each subtree
-    children = [[] for _ in range(ns)]
-    for s in range(ns):                              # parent[s] > s (postorder)
-        p = parent[s]
-        if p >= 0:
-            sub[p] += sub[s]
-            first[p] = min(first[p], first[s])
-            children[p].append(s)
-    total = float(work.sum())
-    owner = np.full(ns, -1, dtype=np.int64)
+    """Returns dict(owner[nsuper] (-1 = top), top_ranges [(lo,hi) Lx offsets], stats).  The partition itself is
+    mi355_partition (C ABI, csrc/multi.hip.hpp): one implementation for C callers and for this module."""
+    from . import engine
+    owner32, top_work, total, loads = engine.partition(sym, world, min_subtrees_per_rank)
+    owner = owner32.astype(np.int64)
     if world <= 1:
-        owner[:] = 0
         return dict(owner=owner, top_ranges=[], top_work=0.0, rank_work=[total], total_work=total)
-    import heapq
-    heap = [(-sub[s], s) for s in range(ns) if parent[s] < 0]
-    heapq.heapify(heap)
-    target = total / (2.0 * world)
-    top = []
-    while heap:
-        w, s = heap[0]
-        enough = len(heap) >= min_subtrees_per_rank * world
-        if (-w <= target and enough) or not children[s]:
-            break                                    # balanced enough, or the heaviest subtree is a leaf
-        heapq.heappop(heap)
-        top.append(s)
-        for c in children[s]:
-            heapq.heappush(heap, (-sub[c], c))
-    # LPT assignment of the remaining subtrees
-    loads = [0.0] * world
-    for w, s in sorted(heap):
-        r = int(np.argmin(loads))
-        loads[r] += -w
-        owner[first[s]:s + 1] = r                    # contiguous: a postordered subtree
-    for s in top:
-        owner[s] = -1
     Lpx = sym["Lpx"]
     ranges = []
-    for s in sorted(top):
+    for s in np.nonzero(owner < 0)[0]:
         lo, hi = int(Lpx[s]), int(Lpx[s + 1])
         if ranges and ranges[-1][1] == lo:
             ranges[-1] = (ranges[-1][0], hi)
         else:
             ranges.append((lo, hi))
-    return dict(owner=owner, top_ranges=ranges, top_work=float(work[top].sum()) if top else 0.0,
-                rank_work=loads, total_work=total)
+    return dict(owner=owner, top_ranges=ranges, top_work=top_work, rank_work=loads, total_work=total)
 
 
 class PartitionedFactor:
@@ -106,10 +73,30 @@ class PartitionedFactor:
     every tensor over the ranks (default: torch.distributed all_reduce = RCCL on GPUs)."""
 
     def __init__(self, factor, sym, rank, world, allreduce=None, min_subtrees_per_rank=2, distribute_top=None,
-                 bcast=None, reduce=None):
+                 bcast=None, reduce=None, comm=None):
+        """comm (an engine.Comm): the whole driver runs behind the C ABI -- mi355_factor_partition,
+        mi355_factor_numeric_multi, mi355_super_solve_multi_dev -- and this class only forwards.  Without comm and
+        without caller-supplied collectives, on an initialised torch.distributed group with the nccl (= RCCL) backend,
+        such a communicator is created here.  The Python driver below remains for callers that bring their own
+        collectives as Python callables (the lockstep harnesses of the tests)."""
         self.f, self.rank, self.world = factor, rank, world
         self.n = int(sym["n"])
         self.Super = sym["Super"]
+        if distribute_top is None:
+            distribute_top = os.environ.get("MI355_TOP", "distributed") != "replicated"
+        if comm is None and allreduce is None and bcast is None and reduce is None and world > 1 \
+                and hasattr(factor, "numeric_multi"):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                import torch
+                from . import engine
+                comm = engine.Comm.from_torch_distributed(torch.cuda.current_device())
+        self.comm = comm
+        if comm is not None:
+            self.owner, self.counts = factor.partition(rank, world, min_subtrees_per_rank, distribute_top)
+            self.status, self.minor = 0, self.n
+            self.dist = self.counts["top_blocks"] > 0
+            return
         self.part = partition(sym, world, min_subtrees_per_rank)
         owner = self.part["owner"]
         local = (owner == rank).astype(np.int8)
@@ -129,8 +116,6 @@ class PartitionedFactor:
         if os.environ.get("MI355_TOP_REDUCE", "owner") == "allreduce":
             self.reduce = None
         self.status, self.minor = 0, self.n
-        if distribute_top is None:
-            distribute_top = os.environ.get("MI355_TOP", "distributed") != "replicated"
         self.dist = bool(distribute_top) and world > 1 and bool(self.part["top_ranges"])
         if self.dist:
             self.plan, (dlo, dhi) = factor.set_top_distribution(rank, world)
@@ -232,6 +217,10 @@ class PartitionedFactor:
         return self.status
 
     def numeric(self, beta=0.0, quick_return_if_not_posdef=False):
+        if self.comm is not None:
+            self.status = self.f.numeric_multi(self.comm, beta, quick_return_if_not_posdef)
+            self.minor = int(self.f.minor)
+            return self.status
         self.status, self.minor = 0, self.n
         bad, info = self.f.numeric_phase(0, beta)
         if self._agree(bad, info) >= 0:
@@ -261,6 +250,8 @@ class PartitionedFactor:
     def lsolve(self, X, nrhs):
         """L x = b (cholmod_super_lsolve): own subtrees, sum over the ranks, top"""
         assert self.status == 0, "no positive-definite factor"
+        if self.comm is not None:
+            return self.f.solve_multi_dev(self.comm, True, X.data_ptr(), nrhs, self.n)
         self.f.keep_rows_dev(X.data_ptr(), nrhs, self.n)
         self.f.solve_phase_dev(0, True, X.data_ptr(), nrhs, self.n)
         self._sum(X)
@@ -269,6 +260,8 @@ class PartitionedFactor:
     def ltsolve(self, X, nrhs):
         """L' x = b (cholmod_super_ltsolve): top, own subtrees, union of the ranks' rows"""
         assert self.status == 0, "no positive-definite factor"
+        if self.comm is not None:
+            return self.f.solve_multi_dev(self.comm, False, X.data_ptr(), nrhs, self.n)
         self.f.solve_phase_dev(1, False, X.data_ptr(), nrhs, self.n)
         self.f.solve_phase_dev(0, False, X.data_ptr(), nrhs, self.n)
         self.f.keep_rows_dev(X.data_ptr(), nrhs, self.n)

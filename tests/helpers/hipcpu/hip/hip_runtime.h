@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 namespace hipcpu {
@@ -101,8 +102,11 @@ template <class F> void launch_serial(int64_t grid, unsigned block, F call)
         for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; lane = (int)(t & 63); call(); }
 }
 // any kernel: `block` host threads (a multiple of 64), each running its lane of workgroup 0, 1, 2, ... in turn
+// __shared__ arrays are function statics here: launches from several host threads (one per simulated rank) take turns
+inline std::mutex launch_mu;
 template <class F> void launch(int64_t grid, unsigned block, F call, unsigned grid_y = 1)
 {
+    std::lock_guard<std::mutex> one_at_a_time(launch_mu);
     Block B;
     const unsigned nw = block / 64;
     pthread_barrier_init(&B.bar, nullptr, block);

@@ -279,80 +279,6 @@ def test_partitioned_factor_through_the_abi(engine, world, spoil, tiny_max):
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(14, 0)
 
 
-WORKER_ENGINE = r'''
-import os, sys
-import numpy as np
-sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
-import torch, torch.distributed as dist
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-from suitesparse_amd import engine, multigpu, symbolic
-engine.LIB_PATH, engine._LIB = {lib!r}, None          # the CPU build of the engine (test infrastructure)
-symbolic._ready = False
-import test_abi_on_cpu as ta
-from test_multigpu import problem
-from oracle import port
-g = dict(problem("lap3d", 6))
-engine.set_tuning(2, 64); engine.set_tuning(7, 64)
-f = ta.EngineFactor(engine, g)
-run = multigpu.PartitionedFactor(f, g, rank, world, min_subtrees_per_rank=1)    # default collectives: dist.reduce / broadcast / all_reduce
-assert run.dist and run.reduce is not None
-st = run.numeric()
-so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
-owner = run.part["owner"]
-worst = 0.0
-for s in range(g["nsuper"]):
-    if owner[s] in (rank, -1):
-        a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
-        nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
-        got, want = f.Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
-        low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
-        worst = max(worst, float(np.abs(got[low] - want[low]).max() / np.abs(Lo).max()))
-b = np.random.default_rng(3).standard_normal((2, g["n"]))
-X = torch.from_numpy(b.copy())
-run.lsolve(X, 2)
-run.ltsolve(X, 2)
-want = port.super_solve(g, Lo, port.super_solve(g, Lo, b.T.copy(), lower=True), lower=False).T
-worst = max(worst, float(np.abs(X.numpy() - want).max() / np.abs(want).max()))
-# a bad pivot: every rank replays the reference's protocol and ends with its minor
-Sx = g["Sx"].copy(); Sx[g["Sp"][g["n"] // 2]] = -4.0
-f.L.set_matrix(g["Sp"], g["Si"], Sx)
-st2 = run.numeric()
-so2, mo2, Lo2 = port.super_numeric(g, g["Sp"], g["Si"], Sx)
-same = bool(np.array_equal(f.Lx == 0, Lo2 == 0)) and float(np.abs(f.Lx - Lo2).max()) < 1e-10 * float(np.abs(Lo2).max())
-with open(os.path.join({out!r}, f"result_{{rank}}.txt"), "w") as fh:
-    fh.write(f"RESULT {{rank}} {{st}} {{worst}} {{st2}} {{run.minor}} {{so2}} {{mo2}} {{int(same)}}\n")
-dist.destroy_process_group()
-'''
-
-
-def test_two_process_gloo_run_on_the_engine(engine, tmp_path):
-    """what bench.py does at N = 2, without a GPU: two processes, each with a real engine handle (CPU build),
-    PartitionedFactor with its default collectives (dist.reduce to the owners, dist.broadcast of finished blocks,
-    all_reduce of the block inverses and of X) over gloo: factor, solves, and a not-positive-definite matrix"""
-    import socket
-    import subprocess
-    import sys
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER_ENGINE.format(root=ROOT, lib=CPUEMU, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    for attempt in range(2):
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                             capture_output=True, text=True, env=env, timeout=900)
-        if out.returncode == 0:
-            break
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    for r in range(2):
-        l = open(tmp_path / f"result_{r}.txt").read().split()
-        st, worst, st2, minor2, so2, mo2, same = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7]), int(l[8])
-        assert st == 0 and worst < 1e-9
-        assert st2 == so2 == 1 and minor2 == mo2 and same == 1
-
-
 @pytest.mark.parametrize("kind,size", [("lap3d", 4), ("helm", 3)])
 def test_every_solve_path_through_the_abi(engine, kind, size):
     """solve_dev's dispatch (tuning keys 9 / 10: scalar or MFMA kernels, grouped or per block; real and complex) through

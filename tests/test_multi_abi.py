@@ -1,0 +1,392 @@
+"""More than one GPU behind the C ABI (csrc/multi.hip.hpp): mi355_partition, mi355_factor_partition,
+mi355_factor_numeric_multi, mi355_super_solve_multi_dev with a mi355_comm.
+
+CPU part: the CPU build of the engine (tests/helpers/libmi355_cpuemu.so, test infrastructure: "device" memory is host
+memory there) with one THREAD per rank and a blocking transport made of Python callbacks over a barrier -- the
+caller-supplied transport of include/mi355_cholmod.h -- and once with two PROCESSES over gloo.  What is checked: every
+rank ends with the oracle's columns of L for its subtrees and the top, the solves on the partitioned factor, the
+not-positive-definite protocol (same status, minor and zero pattern as the reference on every rank), a factor whose
+subtrees are not contiguous index ranges.
+GPU part (-m gpu): the RCCL transport bound at run time, with the one rank a one-GPU box has."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+
+CPUEMU = os.path.join(ROOT, "tests", "helpers", "libmi355_cpuemu.so")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    if not os.path.exists(CPUEMU):
+        pytest.skip("libmi355_cpuemu.so not built (needs /opt/rocm's clang++)")
+    from suitesparse_amd import engine as e, symbolic
+    saved = (e.LIB_PATH, e._LIB)
+    e.LIB_PATH, e._LIB = CPUEMU, None
+    symbolic._ready = False
+    try:
+        assert e.probe() == 1
+        yield e
+    finally:
+        e.LIB_PATH, e._LIB = saved
+        symbolic._ready = False
+
+
+def host_view(ptr, count):
+    return np.ctypeslib.as_array((C.c_double * int(count)).from_address(int(ptr)))
+
+
+class Bus:
+    """blocking collectives among the threads of one process, on host memory; a reduce leaves the other ranks'
+    buffers as they are (partial sums), as a real one does"""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=120)
+        self.slot = [None] * world
+        self.log = [[] for _ in range(world)]
+
+    def comm(self, engine, rank):
+        def reduce_sum(p, n, root):
+            self.log[rank].append(("reduce", n, root))
+            self.slot[rank] = host_view(p, n)
+            self.bar.wait()
+            if rank == root:
+                tot = np.sum([self.slot[r] for r in range(self.world)], axis=0)
+                self.slot[rank][...] = tot
+            self.bar.wait()
+
+        def bcast(p, n, root):
+            self.log[rank].append(("bcast", n, root))
+            self.slot[rank] = host_view(p, n)
+            self.bar.wait()
+            if rank != root:
+                self.slot[rank][...] = self.slot[root]
+            self.bar.wait()
+
+        def allreduce_sum(p, n):
+            self.log[rank].append(("allreduce", n, -1))
+            self.slot[rank] = host_view(p, n)
+            self.bar.wait()
+            tot = np.sum([self.slot[r] for r in range(self.world)], axis=0)
+            self.bar.wait()
+            self.slot[rank][...] = tot
+            self.bar.wait()
+
+        def allreduce_min(v):
+            self.slot[rank] = v
+            self.bar.wait()
+            m = min(self.slot)
+            self.bar.wait()
+            return m
+        return engine.Comm.custom(rank, self.world, reduce_sum, bcast, allreduce_sum, allreduce_min)
+
+
+def run_ranks(world, body):
+    """body(rank) on one thread per rank; re-raises the first failure"""
+    errs = [None] * world
+
+    def wrap(r):
+        try:
+            body(r)
+        except BaseException as e:          # noqa: BLE001 -- reported below
+            errs[r] = e
+    ts = [threading.Thread(target=wrap, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck"
+    for e in errs:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+def check_own_columns(g, owner, rank, Lx, Lo, tol=1e-10):
+    for s in range(g["nsuper"]):
+        if owner[s] in (rank, -1):
+            a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+            nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+            got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+            low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+            assert relerr(got[low], want[low]) < tol, (rank, s)
+
+
+@pytest.mark.parametrize("kind,size,world,dist_top,spoil,ob", [
+    ("lap3d", 6, 3, True, False, 64), ("lap3d", 4, 2, True, True, 64), ("lap3d", 5, 2, False, False, 256),
+    ("lap2d", 16, 4, True, False, 64), ("helm", 4, 2, True, False, 64), ("lap2d", 8, 2, False, True, 256),
+    ("elast", 3, 3, True, False, 64)])
+def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob):
+    from oracle import port
+    from test_multigpu import problem
+    g = dict(problem(kind, size))
+    n = g["n"]
+    cplx = np.iscomplexobj(g["Sx"])
+    if spoil:
+        Sx = g["Sx"].copy()
+        Sx[g["Sp"][n // 2]] = -3.0
+        g["Sx"] = Sx
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert (so != 0) == spoil
+    engine.set_tuning(2, ob); engine.set_tuning(7, ob)
+    bus = Bus(world)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if cplx else 0)
+    want = None if spoil else port.super_solve(g, Lo, port.super_solve(g, Lo, B, lower=True), lower=False)
+    infos = [None] * world
+    try:
+        def body(rank):
+            L = engine.SupernodalFactor(g, xtype=2 if cplx else 1)
+            comm = bus.comm(engine, rank)
+            owner, cnt = L.partition(rank, world, 1, dist_top)
+            infos[rank] = (owner.copy(), cnt)
+            assert cnt["world"] == world and cnt["rank"] == rank
+            assert (cnt["top_blocks"] > 0) == dist_top and cnt["reductions"] == cnt["top_blocks"]
+            L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+            for _ in range(2):                                  # a refactorization reuses everything
+                st = L.numeric_multi(comm, 0.0, False)
+                assert (st, L.minor) == (so, mo)
+                E = 2 if cplx else 1
+                Lx = host_view(L.device_Lx_ptr(), g["xsize"] * E)
+                Lx = Lx.view(np.complex128) if cplx else Lx
+                if spoil:
+                    assert np.array_equal(Lx == 0, Lo == 0) and relerr(Lx, Lo) < 1e-10
+                else:
+                    check_own_columns(g, owner, rank, Lx, Lo)
+            if not spoil:
+                X = np.array(B.T, order="C", copy=True)        # column-major n x 3
+                Xf = X.view(np.float64).reshape(-1)
+                L.solve_multi_dev(comm, True, Xf.ctypes.data, 3, n)
+                L.solve_multi_dev(comm, False, Xf.ctypes.data, 3, n)
+                assert relerr(X.T, want) < 1e-9
+            comm.close()
+            L.close()
+        run_ranks(world, body)
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+    # every rank decided the same partition, and issued the same collectives in the same order
+    for r in range(1, world):
+        assert np.array_equal(infos[r][0], infos[0][0])
+        assert bus.log[r] == bus.log[0]
+    kinds = [k for k, _, _ in bus.log[0]]
+    if dist_top and not spoil:
+        assert kinds.count("reduce") == 2 * infos[0][1]["top_blocks"] == kinds.count("bcast")
+
+
+def test_reductions_start_before_the_subtrees_are_done(engine):
+    """the order of the reductions: a block of the top that only low levels of the subtrees update is summed while the
+    remaining levels are still to be enqueued (mi355_factor_partition_info counts[5..7])"""
+    from test_multigpu import problem
+    g = dict(problem("lap3d", 9))
+    engine.set_tuning(2, 64); engine.set_tuning(7, 64)
+    try:
+        L = engine.SupernodalFactor(g)
+        owner, cnt = L.partition(0, 4, 1, True)
+        assert cnt["top_blocks"] > 0 and cnt["reductions"] == cnt["top_blocks"]
+        assert cnt["steps_before_first_reduce"] <= cnt["steps_before_last_reduce"] <= cnt["own_steps"]
+        assert cnt["steps_before_first_reduce"] < cnt["own_steps"]
+        L.close()
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+
+
+def interleaved_forest():
+    """thirteen one-column supernodes whose subtrees are NOT contiguous index ranges (an analysis without
+    postordering): leaves 0..7, leaf i -> 8 + i % 4, the four middle nodes -> 12"""
+    n = 13
+    rows = {j: [j, 8 + j % 4, 12] for j in range(8)}
+    rows.update({j: [j, 12] for j in range(8, 12)})
+    rows[12] = [12]
+    Super = np.arange(n + 1, dtype=np.int64)
+    Lpi = np.zeros(n + 1, dtype=np.int64)
+    Ls = []
+    for j in range(n):
+        Ls += rows[j]
+        Lpi[j + 1] = len(Ls)
+    Ls = np.array(Ls, dtype=np.int64)
+    g = dict(n=n, nsuper=n, ssize=len(Ls), xsize=len(Ls), maxcsize=4, maxesize=2, Super=Super, Lpi=Lpi, Lpx=Lpi.copy(), Ls=Ls)
+    # S = lower triangle with that pattern, diagonally dominant
+    Sp, Si, Sx = Lpi.copy(), Ls.copy(), np.zeros(len(Ls))
+    for j in range(n):
+        for p in range(int(Lpi[j]), int(Lpi[j + 1])):
+            Sx[p] = 10.0 + j if Ls[p] == j else -1.0 - 0.1 * p
+    g.update(Sp=Sp, Si=Si, Sx=Sx)
+    return g
+
+
+def test_partition_of_a_factor_that_is_not_postordered(engine):
+    from oracle import port
+    g = interleaved_forest()
+    n = g["n"]
+    owner, top_work, total, loads = engine.partition(g, 2, 1)
+    assert owner[12] == -1 and (owner[:12] >= 0).all()
+    for j in range(8):                                  # a subtree stays whole although its indices are scattered
+        assert owner[j] == owner[8 + j % 4]
+    assert sorted(np.bincount(owner[8:12], minlength=2).tolist()) == [2, 2]
+    assert abs(sum(loads) + top_work - total) < 1e-9
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert so == 0
+    bus = Bus(2)
+
+    def body(rank):
+        L = engine.SupernodalFactor(g)
+        comm = bus.comm(engine, rank)
+        own, _ = L.partition(rank, 2, 1, True)
+        assert np.array_equal(own, owner)
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        assert L.numeric_multi(comm) == 0
+        check_own_columns(g, own, rank, host_view(L.device_Lx_ptr(), g["xsize"]), Lo)
+        b = np.arange(1.0, n + 1.0)
+        x = b.copy()
+        L.solve_multi_dev(comm, True, x.ctypes.data, 1, n)
+        L.solve_multi_dev(comm, False, x.ctypes.data, 1, n)
+        assert relerr(x, port.super_solve(g, Lo, port.super_solve(g, Lo, b[:, None], True), False)[:, 0]) < 1e-12
+        comm.close(); L.close()
+    run_ranks(2, body)
+
+
+def test_partition_rejects_a_parent_that_does_not_come_later(engine):
+    g = interleaved_forest()
+    Ls = g["Ls"].copy()
+    # supernode 9's first row below its column becomes row 2: its parent would be supernode 2 < 9
+    Ls[int(g["Lpi"][9]) + 1] = 2
+    bad = dict(g, Ls=Ls)
+    with pytest.raises(engine.Mi355Error) as ei:
+        engine.partition(bad, 2, 1)
+    assert ei.value.code == engine.CHOLMOD_INVALID
+
+
+def test_argument_checks(engine):
+    from test_multigpu import problem
+    g = dict(problem("lap3d", 4))
+    L = engine.SupernodalFactor(g)
+    bus = Bus(1)
+    c1 = bus.comm(engine, 0)
+    with pytest.raises(engine.Mi355Error):             # no partition yet
+        L.numeric_multi(c1)
+    L.partition(0, 2, 1, True)
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    with pytest.raises(engine.Mi355Error) as ei:       # the communicator's world differs from the partition's
+        L.numeric_multi(c1)
+    assert "rank/world" in str(ei.value)
+    with pytest.raises(engine.Mi355Error):
+        L.partition(2, 2, 1, True)
+    # world 1: the plain factorization
+    L.partition(0, 1, 1, True)
+    assert L.numeric_multi(c1) == 0
+    from oracle import port
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert relerr(L.Lx(), Lo) < 1e-10
+    # a transport without its callbacks is refused for world > 1
+    t = engine._Transport(0, 2, None)
+    h = C.c_void_p()
+    assert engine.lib().mi355_comm_create(C.byref(t), C.byref(h)) == engine.CHOLMOD_INVALID
+    c1.close(); L.close()
+
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from suitesparse_amd import engine, multigpu, symbolic
+engine.LIB_PATH, engine._LIB = {lib!r}, None          # the CPU build of the engine (test infrastructure)
+symbolic._ready = False
+from test_multigpu import problem
+from test_multi_abi import host_view, check_own_columns
+from oracle import port
+g = dict(problem("lap3d", 6))
+engine.set_tuning(2, 64); engine.set_tuning(7, 64)
+view = lambda p, n: torch.from_numpy(host_view(p, n))
+def amin(v):
+    t = torch.tensor([v], dtype=torch.int64); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item())
+comm = engine.Comm.custom(rank, world,
+                          lambda p, n, root: dist.reduce(view(p, n), dst=root),
+                          lambda p, n, root: dist.broadcast(view(p, n), src=root),
+                          lambda p, n: dist.all_reduce(view(p, n)), amin)
+L = engine.SupernodalFactor(g)
+run = multigpu.PartitionedFactor(L, g, rank, world, min_subtrees_per_rank=1, comm=comm)   # forwards to the C driver
+L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+st = run.numeric()
+so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+check_own_columns(g, run.owner, rank, host_view(L.device_Lx_ptr(), g["xsize"]), Lo)
+b = np.random.default_rng(3).standard_normal((2, g["n"]))
+X = torch.from_numpy(b.copy())
+run.lsolve(X, 2)
+run.ltsolve(X, 2)
+want = port.super_solve(g, Lo, port.super_solve(g, Lo, b.T.copy(), lower=True), lower=False).T
+worst = float(np.abs(X.numpy() - want).max() / np.abs(want).max())
+Sx = g["Sx"].copy(); Sx[g["Sp"][g["n"] // 2]] = -4.0
+L.set_matrix(g["Sp"], g["Si"], Sx)
+st2 = run.numeric()
+so2, mo2, Lo2 = port.super_numeric(g, g["Sp"], g["Si"], Sx)
+Lx = host_view(L.device_Lx_ptr(), g["xsize"])
+same = bool(np.array_equal(Lx == 0, Lo2 == 0)) and float(np.abs(Lx - Lo2).max()) < 1e-10 * float(np.abs(Lo2).max())
+with open(os.path.join({out!r}, f"result_{{rank}}.txt"), "w") as fh:
+    fh.write(f"RESULT {{rank}} {{st}} {{worst}} {{st2}} {{run.minor}} {{so2}} {{mo2}} {{int(same)}} {{run.counts['top_blocks']}}\n")
+comm.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_run_of_the_c_driver(engine, tmp_path):
+    """two processes, the transport callbacks over gloo: mi355_factor_numeric_multi, the solves, a bad pivot"""
+    import socket
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, lib=CPUEMU, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                             capture_output=True, text=True, env=env, timeout=900)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    for r in range(2):
+        l = open(tmp_path / f"result_{r}.txt").read().split()
+        st, worst, st2, minor2, so2, mo2, same, blocks = int(l[2]), float(l[3]), int(l[4]), int(l[5]), int(l[6]), \
+            int(l[7]), int(l[8]), int(l[9])
+        assert st == 0 and worst < 1e-9 and blocks > 0
+        assert st2 == so2 == 1 and minor2 == mo2 and same == 1
+
+
+@pytest.mark.gpu
+def test_rccl_transport_binds_and_runs_with_one_rank():
+    """the RCCL transport on the one GPU of the box: librccl is found and bound at run time (ncclGetUniqueId,
+    ncclCommInitRank with the 128-byte id by value), the communicator's stream and key buffer exist, and
+    mi355_factor_numeric_multi / _solve_multi_dev with world 1 are the plain calls.  (More ranks need more GPUs: the
+    N > 1 order of operations is what the CPU tests above cover.)"""
+    from suitesparse_amd import engine
+    from oracle import port
+    from test_multigpu import problem
+    import torch
+    g = dict(problem("lap3d", 10))
+    comm = engine.Comm.rccl(0, 1, 0, lambda idb: idb)
+    L = engine.SupernodalFactor(g)
+    L.partition(0, 1, 2, True)
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    assert L.numeric_multi(comm) == 0
+    so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+    assert relerr(L.Lx(), Lo) < 1e-10
+    b = np.random.default_rng(0).standard_normal((2, g["n"]))
+    X = torch.from_numpy(b.copy()).cuda()
+    L.solve_multi_dev(comm, True, X.data_ptr(), 2, g["n"])
+    L.solve_multi_dev(comm, False, X.data_ptr(), 2, g["n"])
+    want = port.super_solve(g, Lo, port.super_solve(g, Lo, b.T.copy(), lower=True), lower=False).T
+    assert relerr(X.cpu().numpy(), want) < 1e-9
+    comm.close()
+    L.close()
