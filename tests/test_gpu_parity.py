@@ -451,6 +451,61 @@ def test_full_size_properties(engine, grid):
     assert float((X2 - Y0).abs().max()) < 1e-9 * float(Y0.abs().max())
 
 
+def _named_problem(kind, grid):
+    from suitesparse_amd import problems, symbolic
+    p = {"lap2d": problems.laplacian_2d, "lap3d": problems.laplacian_3d, "elast": problems.elasticity27,
+         "helm": problems.helmholtz_3d}[kind](grid)
+    perm = symbolic.nd_grid_order(p["shape"], p["dof"])
+    sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], perm)
+    Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
+    return p, sym, Sp, Si, Sx
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,grid,nrhs", [("lap2d", 2000, 3), ("elast", 80, 3), ("helm", 100, 64)])
+def test_full_size_properties_of_the_other_configs(engine, kind, grid, nrhs):
+    """BASELINE configs 2, 4 and 5 at their stated sizes (2D 2000^2; 27-point 3-dof 80^3; complex Hermitian Helmholtz
+    100^3 with 64 right-hand sides), checked through size-independent properties: the backward error
+    ||A x - b||_inf / (||A||_inf ||x||_inf + ||b||_inf) of every column at rounding level, b = A*1 solves back to 1,
+    the solve is linear (last column = a combination of the first two), and a refactorization reproduces the
+    solution to the atomics' summation-order noise."""
+    import scipy.sparse as sp
+    import torch
+    p, sym, Sp, Si, Sx = _named_problem(kind, grid)
+    n = p["n"]
+    cplx = np.iscomplexobj(Sx)
+    S = sp.csc_matrix((Sx, Si, Sp), shape=(n, n))
+    A = (S + S.conj().T - sp.diags(S.diagonal().real)).tocsr()
+    L = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    L.set_matrix(Sp, Si, Sx)
+    assert L.numeric() == 0 and L.minor == n
+    rng = np.random.default_rng(grid)
+    dt = np.complex128 if cplx else np.float64
+    B = np.empty((n, nrhs), dtype=dt)
+    B[:, 0] = A @ np.ones(n)
+    for j in range(1, nrhs - 1):
+        B[:, j] = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    B[:, nrhs - 1] = 2.0 * B[:, 0] - 3.0 * B[:, 1]
+
+    def solve():
+        X = torch.from_numpy(np.ascontiguousarray(B.T).view(np.float64).copy()).cuda()   # column-major n x nrhs
+        L.solve_dev(X.data_ptr(), nrhs, n, lower=True)
+        L.solve_dev(X.data_ptr(), nrhs, n, lower=False)
+        return X
+    X = solve()
+    Xh = X.cpu().numpy().reshape(nrhs, -1)
+    Xh = (Xh.view(np.complex128) if cplx else Xh).T                                      # n x nrhs
+    anorm = abs(A).sum(axis=1).max()
+    R = A @ Xh - B
+    for j in range(nrhs):
+        assert np.abs(R[:, j]).max() / (anorm * np.abs(Xh[:, j]).max() + np.abs(B[:, j]).max()) < 1e-13, j
+    assert np.abs(Xh[:, 0] - 1.0).max() < 1e-8
+    assert np.abs(Xh[:, -1] - (2.0 * Xh[:, 0] - 3.0 * Xh[:, 1])).max() < 1e-9 * np.abs(Xh).max()
+    assert L.numeric() == 0
+    X2 = solve()
+    assert float((X2 - X).abs().max()) < 1e-9 * float(X.abs().max())
+
+
 def test_not_posdef_minor_at_scale(engine):
     """one negated diagonal entry at a known permuted column k of a 60^3 Laplacian: the pivot of column k is
     the first that fails, so L->minor = k exactly and the columns from k on are zero (worker :1084-1146)."""
