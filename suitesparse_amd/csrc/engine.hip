@@ -424,6 +424,11 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
         return fail(MI355_INVALID, "factor xtype must be MI355_REAL or MI355_COMPLEX (a zomplex A gives a complex L)");
     if (n < 0 || nsuper < 0 || ssize < 0 || xsize < 0) return fail(MI355_INVALID, "negative size");
     if (nsuper > 0 && (!Super || !Lpi || !Lpx || !Ls)) return fail(MI355_INVALID, "null symbolic array");
+    // before anything of length n is read: the reference reports an index that overflows the BLAS integer as
+    // CHOLMOD_TOO_LARGE (t_cholmod_super_numeric_worker.c:183-188, cholmod_super_numeric.c:202); here the narrow type is
+    // the kernels' int32 row index
+    if (n >= (int64_t(1) << 31) - 1)
+        return fail(MI355_TOO_LARGE, "too large: n does not fit the 32-bit row indices of the device kernels");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MI355_GPU_PROBLEM, "no HIP device available (this library has no CPU path)");
@@ -456,6 +461,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     F->sym.Super = F->Super.data(); F->sym.Lpi = F->Lpi.data();
     F->sym.Lpx = F->Lpx.data(); F->sym.Ls = F->Ls.data();
     const std::string bad = validate_symbolic(F->sym);
+    if (bad.compare(0, 10, "too large:") == 0) return fail(MI355_TOO_LARGE, bad);
     if (!bad.empty()) return fail(MI355_INVALID, "invalid supernodal symbolic factor: " + bad);
 
     F->sym.cplx = (F->E == 2);          // the big-tile kernel then covers 64 x 128 complex entries per tile

@@ -38,7 +38,7 @@ std::string validate_symbolic(const Symbolic &S)
     if (S.n < 0 || S.nsuper < 0) return "negative dimension";
     if (S.n == 0 || S.nsuper == 0) return (S.n == 0 && S.nsuper == 0) ? "" : "n/nsuper mismatch";
     if (!S.Super || !S.Lpi || !S.Lpx || !S.Ls) return "null symbolic array";
-    if (S.n >= (int64_t(1) << 31) - 1) return "n too large for 32-bit row indices";
+    if (S.n >= (int64_t(1) << 31) - 1) return "too large: n does not fit the 32-bit row indices of the device kernels";
     if (S.Super[0] != 0 || S.Super[S.nsuper] != S.n) return "Super does not span 0..n";
     if (S.Lpi[0] != 0 || S.Lpx[0] != 0) return "Lpi[0]/Lpx[0] must be 0";
     for (int64_t s = 0; s < S.nsuper; s++) {

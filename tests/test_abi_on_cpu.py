@@ -350,3 +350,58 @@ def test_complex_solve2_with_permutation(engine):
     assert relerr(L.solve(B, 4), np.linalg.solve(Ld, B)) < 1e-9           # CHOLMOD_L
     assert relerr(L.solve(B, 5), np.linalg.solve(Ld.conj().T, B)) < 1e-9  # CHOLMOD_Lt
     L.close()
+
+
+def test_too_large_is_reported_not_wrapped(engine):
+    """SURVEY 8 row a9 (BLAS int narrowing): the reference guards every narrowing of its int64 sizes to the BLAS integer
+    and reports CHOLMOD_TOO_LARGE (t_cholmod_super_numeric_worker.c:183-188, cholmod_super_numeric.c:202).  Here the
+    narrow types are the kernels' int32 row indices and launch counts: n >= 2^31 - 1 is refused by mi355_factor_create
+    before any array of that length is read, and more right-hand sides than one launch can index by the solves"""
+    import ctypes as C
+    CHOLMOD_TOO_LARGE = -3
+    one = np.zeros(2, dtype=np.int64)
+    h = C.c_void_p()
+    n = (1 << 31) - 1
+    Super = np.array([0, n], dtype=np.int64)
+    rc = engine.lib().mi355_factor_create(1, n, 1, Super, Super, np.array([0, n * n], dtype=np.int64), one, n, n * n, 0,
+                                          C.byref(h))
+    assert rc == CHOLMOD_TOO_LARGE and not h.value
+    assert b"too large" in engine.lib().mi355_last_error()
+    g = load_golden("demo_bcsstk01")
+    L = engine.SupernodalFactor(sym_of(g))
+    assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == 0
+    x = np.zeros(g["n"])
+    for fn in (engine.lib().mi355_super_lsolve_dev, engine.lib().mi355_super_ltsolve_dev):
+        assert fn(L._h, (1 << 30), C.c_void_p(x.ctypes.data), g["n"]) == CHOLMOD_TOO_LARGE
+    assert engine.lib().mi355_solve_dev(L._h, 0, (1 << 30), C.c_void_p(x.ctypes.data), g["n"],
+                                        C.c_void_p(x.ctypes.data), g["n"]) == CHOLMOD_TOO_LARGE
+    L.close()
+
+
+def test_blas_timer_statistics(engine):
+    """SURVEY 8 row a10 (the -DBLAS_TIMER counters, worker :246-266,:763-811): with profiling on, every launch is
+    bracketed; the launch counts equal the schedule's steps, the kernel times are positive and add up to no more than
+    the call, and a call with profiling off reports counts but no kernel times"""
+    from test_multigpu import problem
+    g = dict(problem("lap3d", 5))
+    L = engine.SupernodalFactor(g)
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    L.set_profile(True)
+    assert L.numeric() == 0
+    st = L.stats()
+    assert st["gemm_launches"] > 0 and st["potrf_launches"] > 0
+    assert st["gemm_ms"] > 0 and st["potrf_ms"] > 0 and st["assembly_ms"] > 0
+    assert st["gemm128_ms"] <= st["gemm_ms"] and st["gemm128_launches"] <= st["gemm_launches"]
+    assert st["gemm_ms"] + st["potrf_ms"] + st["assembly_ms"] <= st["total_ms"] * 1.001
+    assert st["gemm_tiles"] == st["tiles_gemm128"] + st["tiles_gemm64"]
+    assert st["flops_update"] > 0 and st["flops_panel"] > 0 and st["npairs"] > 0 and st["nlevels"] > 0
+    n1 = (st["gemm_launches"], st["potrf_launches"])
+    assert L.numeric() == 0                             # counts are per call, not cumulative
+    st2 = L.stats()
+    assert (st2["gemm_launches"], st2["potrf_launches"]) == n1
+    L.set_profile(False)
+    assert L.numeric() == 0
+    st3 = L.stats()
+    assert (st3["gemm_launches"], st3["potrf_launches"]) == n1 and st3["total_ms"] > 0
+    assert st3["gemm_ms"] == st2["gemm_ms"]             # nothing new was measured: the last profiled call's times stay
+    L.close()

@@ -748,3 +748,15 @@ def test_multi_rhs_solve_on_mfma(engine, kind, size, nrhs, have_ref):
     # column j of a multi-RHS solve equals the single-RHS solve of that column (same kernels or not)
     j = nrhs // 2
     assert relerr(L.super_ltsolve(L.super_lsolve(B[:, j])), L.super_ltsolve(L.super_lsolve(B))[:, j]) < 1e-10
+
+
+def test_too_large_is_reported_not_wrapped(engine):
+    """SURVEY 8 row a9 on the device library (body shared with the CPU build's test)"""
+    import test_abi_on_cpu as t
+    t.test_too_large_is_reported_not_wrapped(engine)
+
+
+def test_blas_timer_statistics(engine):
+    """SURVEY 8 row a10 on the device library: per-launch HIP events, counts and times"""
+    import test_abi_on_cpu as t
+    t.test_blas_timer_statistics(engine)
