@@ -465,3 +465,130 @@ int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
 #else
 int ref_live_handles (void) { return -1 ; }
 #endif
+
+// Common-> options the reference's test_solver varies (CHOLMOD/Tcov/t_solve.c:61-124)
+int ref_set_option (void *hv, const char *name, double v)
+{
+    cholmod_common *cm = &((ref_ctx *) hv)->cm ;
+    if (!strcmp (name, "final_asis")) cm->final_asis = (int) v ;
+    else if (!strcmp (name, "final_super")) cm->final_super = (int) v ;
+    else if (!strcmp (name, "final_ll")) cm->final_ll = (int) v ;
+    else if (!strcmp (name, "final_pack")) cm->final_pack = (int) v ;
+    else if (!strcmp (name, "final_monotonic")) cm->final_monotonic = (int) v ;
+    else if (!strcmp (name, "final_resymbol")) cm->final_resymbol = (int) v ;
+    else if (!strcmp (name, "nrelax0")) cm->nrelax [0] = (size_t) v ;
+    else if (!strcmp (name, "nrelax1")) cm->nrelax [1] = (size_t) v ;
+    else if (!strcmp (name, "nrelax2")) cm->nrelax [2] = (size_t) v ;
+    else if (!strcmp (name, "zrelax0")) cm->zrelax [0] = v ;
+    else if (!strcmp (name, "zrelax1")) cm->zrelax [1] = v ;
+    else if (!strcmp (name, "zrelax2")) cm->zrelax [2] = v ;
+    else if (!strcmp (name, "grow0")) cm->grow0 = v ;
+    else if (!strcmp (name, "grow1")) cm->grow1 = v ;
+    else if (!strcmp (name, "grow2")) cm->grow2 = (size_t) v ;
+    else if (!strcmp (name, "nthreads_max")) cm->nthreads_max = (int) v ;
+    else return -1 ;
+    return 0 ;
+}
+
+// The expert sequence of the reference's raw_factor test (CHOLMOD/Tcov/t_raw_factor.c:109-340), through the public
+// API: no fill-reducing ordering, alloc_factor -> etree -> postorder -> rowcolcounts -> super_symbolic ->
+// super_numeric -> super_lsolve -> super_ltsolve, and -- check_errors -- every wrong-argument call of that test,
+// each of which must be refused.  The matrix is the loaded one (one triangle stored, either).  The factor is kept as
+// the context's factor.  out[6]: residual ||Ax-b||_inf / (||A||_inf ||x||_inf + ||b||_inf) with b = 1 + i/n,
+// refusals seen, refusals expected, Common->status after super_numeric, L->minor, 1 if every step that must succeed did.
+int ref_raw_factor (void *hv, int check_errors, double *out)
+{
+    ref_ctx *h = hv ;
+    cholmod_common *cm = &h->cm ;
+    if (!h->A || h->A->stype == 0) return -1 ;
+    const int64_t n = h->A->nrow ;
+    double zero [2] = { 0, 0 }, one [2] = { 1, 0 }, minusone [2] = { -1, 0 } ;
+    int refused = 0, expected = 0, good = 1 ;
+    #define MUST(e) do { if (!(e)) good = 0 ; } while (0)
+    #define MUSTNOT(e) do { expected++ ; if (!(e)) refused++ ; } while (0)
+    cholmod_sparse *AU = (h->A->stype > 0) ? cholmod_l_copy_sparse (h->A, cm) : cholmod_l_transpose (h->A, 2, cm) ;
+    cholmod_sparse *AL = cholmod_l_transpose (AU, 2, cm) ;
+    int64_t *Parent = malloc ((n + 1) * sizeof (int64_t)), *Post = malloc ((n + 1) * sizeof (int64_t)),
+            *First = malloc ((n + 1) * sizeof (int64_t)), *Level = malloc ((n + 1) * sizeof (int64_t)) ;
+    cholmod_l_free_factor (&h->L, cm) ;
+    cholmod_factor *L = cholmod_l_allocate_factor (n, cm) ;
+    h->L = L ;
+    MUST (AU && AL && L && AL->stype == -1) ;
+    MUST (cholmod_l_etree (AU, Parent, cm)) ;
+    MUST (cholmod_l_postorder (Parent, n, NULL, Post, cm) >= 0) ;
+    MUST (cholmod_l_rowcolcounts (AL, NULL, 0, Parent, Post, NULL, L->ColCount, First, Level, cm)) ;
+    if (check_errors) MUSTNOT (cholmod_l_rowcolcounts (AU, NULL, 0, Parent, Post, NULL, L->ColCount, First, Level, cm)) ;
+    MUST (cholmod_l_super_symbolic (AU, NULL, Parent, L, cm)) ;
+    if (check_errors)
+    {
+        MUSTNOT (cholmod_l_super_symbolic (AU, NULL, Parent, L, cm)) ;          // L is already supernodal
+        MUSTNOT (cholmod_l_super_symbolic (AL, NULL, Parent, L, cm)) ;
+        MUSTNOT (cholmod_l_super_symbolic (NULL, NULL, Parent, L, cm)) ;
+        MUSTNOT (cholmod_l_super_symbolic (AU, NULL, NULL, L, cm)) ;
+        MUSTNOT (cholmod_l_super_symbolic (AU, NULL, Parent, NULL, cm)) ;
+    }
+    cm->status = CHOLMOD_OK ;
+    MUST (cholmod_l_super_numeric (AL, NULL, zero, L, cm)) ;
+    const int st = cm->status ;
+    if (check_errors)
+    {
+        MUSTNOT (cholmod_l_super_numeric (AU, NULL, zero, L, cm)) ;            // upper form
+        MUSTNOT (cholmod_l_super_numeric (NULL, NULL, zero, L, cm)) ;
+        MUSTNOT (cholmod_l_super_numeric (AL, NULL, zero, NULL, cm)) ;
+        // the refused calls must not have disturbed the factor: factorize again
+        cm->status = CHOLMOD_OK ;
+        MUST (cholmod_l_super_numeric (AL, NULL, zero, L, cm)) ;
+        MUST (cm->status == st) ;
+    }
+    const int lxt = L->xtype ;
+    const int E = (lxt == CHOLMOD_COMPLEX) ? 2 : 1 ;
+    cholmod_dense *B = cholmod_l_zeros (n, 1, lxt + CHOLMOD_DOUBLE, cm) ;
+    for (int64_t i = 0 ; i < n ; i++) ((double *) B->x) [E * i] = 1 + (double) i / (double) (n > 0 ? n : 1) ;
+    cholmod_dense *W = cholmod_l_zeros (n, 1, lxt + CHOLMOD_DOUBLE, cm) ;
+    cholmod_dense *X = cholmod_l_copy_dense (B, cm) ;
+    double r = -1 ;
+    if (st == CHOLMOD_OK)
+    {
+        MUST (cholmod_l_super_lsolve (L, X, W, cm)) ;
+        MUST (cholmod_l_super_ltsolve (L, X, W, cm)) ;
+        // R = B - A X
+        cholmod_dense *R = cholmod_l_copy_dense (B, cm) ;
+        cholmod_l_sdmult (AU, 0, minusone, one, X, R, cm) ;
+        const double rn = cholmod_l_norm_dense (R, 0, cm), xn = cholmod_l_norm_dense (X, 0, cm),
+                     bn = cholmod_l_norm_dense (B, 0, cm), an = cholmod_l_norm_sparse (AU, 0, cm) ;
+        r = rn / (an * xn + bn + (n == 0 ? 1 : 0)) ;
+        cholmod_l_free_dense (&R, cm) ;
+        if (check_errors)
+        {
+            MUSTNOT (cholmod_l_super_lsolve (NULL, X, W, cm)) ;
+            MUSTNOT (cholmod_l_super_ltsolve (NULL, X, W, cm)) ;
+            MUSTNOT (cholmod_l_super_lsolve (L, NULL, W, cm)) ;
+            MUSTNOT (cholmod_l_super_ltsolve (L, NULL, W, cm)) ;
+            MUSTNOT (cholmod_l_super_lsolve (L, X, NULL, cm)) ;
+            MUSTNOT (cholmod_l_super_ltsolve (L, X, NULL, cm)) ;
+            if (L->maxesize > 1)
+            {
+                cholmod_dense *W1 = cholmod_l_zeros (1, 1, lxt + CHOLMOD_DOUBLE, cm) ;      // W is too small
+                MUSTNOT (cholmod_l_super_lsolve (L, X, W1, cm)) ;
+                MUSTNOT (cholmod_l_super_ltsolve (L, X, W1, cm)) ;
+                cholmod_l_free_dense (&W1, cm) ;
+            }
+            cholmod_dense *X2 = cholmod_l_zeros (n + 1, 1, lxt + CHOLMOD_DOUBLE, cm) ;      // wrong dimensions
+            MUSTNOT (cholmod_l_super_lsolve (L, X2, W, cm)) ;
+            MUSTNOT (cholmod_l_super_ltsolve (L, X2, W, cm)) ;
+            cholmod_l_free_dense (&X2, cm) ;
+        }
+        cholmod_dense *X0 = cholmod_l_zeros (n, 0, lxt + CHOLMOD_DOUBLE, cm) ;              // n-by-0 is fine
+        MUST (cholmod_l_super_lsolve (L, X0, W, cm)) ;
+        MUST (cholmod_l_super_ltsolve (L, X0, W, cm)) ;
+        cholmod_l_free_dense (&X0, cm) ;
+    }
+    out [0] = r ; out [1] = refused ; out [2] = expected ; out [3] = st ; out [4] = (double) L->minor ; out [5] = good ;
+    cholmod_l_free_dense (&X, cm) ; cholmod_l_free_dense (&W, cm) ; cholmod_l_free_dense (&B, cm) ;
+    cholmod_l_free_sparse (&AU, cm) ; cholmod_l_free_sparse (&AL, cm) ;
+    free (Parent) ; free (Post) ; free (First) ; free (Level) ;
+    h->last_status = cm->status = st ;
+    #undef MUST
+    #undef MUSTNOT
+    return 0 ;
+}

@@ -89,6 +89,8 @@ def _prototypes(L):
     L.ref_counters.argtypes = [C.c_void_p, f64p]
     L.ref_drop_factor.argtypes = [C.c_void_p]
     L.ref_make_simplicial.argtypes = [C.c_void_p, C.c_int]
+    L.ref_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.ref_raw_factor.argtypes = [C.c_void_p, C.c_int, f64p]
 
 
 class RefCholmod:
@@ -138,6 +140,22 @@ class RefCholmod:
 
     def make_simplicial(self, to_ll=True):
         return int(self.L.ref_make_simplicial(self.h, 1 if to_ll else 0))
+
+    def set_option(self, **kw):
+        """Common-> options the reference's test_solver varies: final_asis, final_super, final_ll, final_pack,
+        final_monotonic, final_resymbol, nrelax0..2, zrelax0..2, grow0..2, nthreads_max"""
+        for k, v in kw.items():
+            if self.L.ref_set_option(self.h, k.encode(), float(v)) != 0:
+                raise KeyError(k)
+
+    def raw_factor(self, check_errors=True):
+        """the expert sequence of CHOLMOD/Tcov/t_raw_factor.c on the loaded matrix (natural ordering); the factor
+        becomes this object's factor"""
+        out = np.zeros(6)
+        if self.L.ref_raw_factor(self.h, int(bool(check_errors)), out) != 0:
+            raise RuntimeError("ref_raw_factor: no symmetric matrix loaded")
+        return dict(resid=float(out[0]), refused=int(out[1]), expected=int(out[2]), status=int(out[3]),
+                    minor=int(out[4]), ok=bool(out[5]))
 
     # ---- matrix ----
     def load(self, n, Ap, Ai, Ax, stype=-1):

@@ -277,3 +277,77 @@ def test_integration_md_lists_what_is_compiled():
         for _, _, ins in edits:
             for ln in ins or ():
                 assert ln.strip() in doc, (rel, ln)
+
+
+def _both_builds(which, g):
+    """(drop-in build, unchanged reference), the same matrix loaded into each"""
+    from oracle import refcholmod
+    r = _cholmod(which)
+    u = refcholmod.RefCholmod()
+    for x in (r, u):
+        x.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    return r, u
+
+
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_c30lo_singular"],
+                                             ["tcov_z30lo", "lap3d_8_metis", "lap2d_16_npd0"]))
+def test_raw_factor_expert_sequence(which, name):
+    """The reference's own raw_factor test (CHOLMOD/Tcov/t_raw_factor.c:109-340) through the patched build: no
+    ordering, alloc_factor -> etree -> postorder -> rowcolcounts -> super_symbolic -> super_numeric -> super_lsolve ->
+    super_ltsolve called one by one, plus every wrong-argument call of that test -- each must be refused exactly as
+    the unchanged build refuses it (the hooks sit behind the wrappers' own checks) -- and the same residual, status
+    and minor as the unchanged build on the same matrix."""
+    g = load_golden(name)
+    r, u = _both_builds(which, g)
+    got, want = r.raw_factor(True), u.raw_factor(True)
+    assert want["ok"] and want["refused"] == want["expected"] >= 9
+    assert got["ok"] and (got["refused"], got["expected"]) == (want["refused"], want["expected"])
+    assert (got["status"], got["minor"]) == (want["status"], want["minor"])
+    c = r.counters()
+    assert c["L_useGPU"] == 1 and c["gpu_gemm_calls"] + c["gpu_potrf_calls"] > 0 and c["cpu_blas_calls"] == 0, c
+    if want["status"] == 0:
+        assert want["resid"] < 1e-12 and got["resid"] < max(10 * want["resid"], 1e-14)
+        assert relerr(r.Lx(), u.Lx()) < 1e-10
+    else:
+        assert got["status"] == NOT_POSDEF
+        assert np.array_equal(r.Lx() == 0, u.Lx() == 0) and relerr(r.Lx(), u.Lx()) < 1e-10
+    r.close(); u.close()
+
+
+SOLVER_SETTINGS = {      # CHOLMOD/Tcov/t_solve.c:61-124, the supernodal runs of test_solver
+    "supernodal": dict(nthreads_max=-1),
+    "no_final_resymbol": dict(final_resymbol=0),
+    "final_super_false": dict(final_asis=0, final_resymbol=1, final_super=0),
+    "final_super_true": dict(final_asis=0, final_resymbol=1, final_super=1),
+    "no_relaxed_supernodes": dict(final_asis=1, nrelax0=0, nrelax1=0, nrelax2=0, zrelax0=0, zrelax1=0, zrelax2=0,
+                                  grow0=1, grow1=1, grow2=0),
+}
+
+
+@pytest.mark.parametrize("which", BOTH)
+@pytest.mark.parametrize("setting", list(SOLVER_SETTINGS))
+def test_solver_settings_of_the_reference(which, setting):
+    """test_solver's supernodal runs: cm->supernodal = CHOLMOD_SUPERNODAL under the final_* / relaxation settings the
+    reference varies; analyze -> factorize -> solve must give the unchanged build's answer, whatever form the factor
+    is left in (final_super = FALSE converts it to simplicial right after the numeric phase: the device image must
+    be gone and the solve runs on the CPU)"""
+    for name in ("demo_bcsstk02", "demo_c"):
+        g = load_golden(name)
+        r, u = _both_builds(which, g)
+        base = r.live_handles()
+        for x in (r, u):
+            x.set_option(**SOLVER_SETTINGS[setting])
+            x.analyze(perm=g["Perm"], supernodal=2)
+            assert x.factorize_full() == 0
+        ir, iu = r.info(), u.info()
+        assert (ir["is_super"], ir["is_ll"], ir["minor"]) == (iu["is_super"], iu["is_ll"], iu["minor"])
+        assert r.counters()["gpu_gemm_calls"] + r.counters()["gpu_potrf_calls"] > 0
+        assert r.live_handles() == base + (1 if ir["is_super"] else 0)
+        if ir["is_super"]:
+            for k in ("Super", "Lpi", "Lpx", "Ls"):
+                assert np.array_equal(r.symbolic()[k], u.symbolic()[k]), k
+            assert relerr(r.Lx(), u.Lx()) < 1e-10
+        X, Xu = r.solve(g["B"]), u.solve(g["B"])
+        assert relerr(X, Xu) < 1e-9
+        assert _demo_resid(_dense_A(g), X, g["B"]) < 1e-7
+        r.close(); u.close()
