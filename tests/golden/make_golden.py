@@ -122,6 +122,7 @@ if __name__ == "__main__":
     from_file("demo_bcsstk01", f"{REF}/Demo/Matrix/bcsstk01.tri")
     from_file("demo_bcsstk02", f"{REF}/Demo/Matrix/bcsstk02.tri")
     from_file("demo_c", f"{REF}/Demo/Matrix/c.tri")
+    from_file("demo_can24", f"{REF}/Demo/Matrix/can___24.mtx")     # pattern-only: cholmod_read_sparse supplies the values
     for t in ["20lo", "k01up", "ex5lo", "r5lo", "r5lo2", "c10", "c30up", "c30lo_singular", "z30lo", "c5up2", "z5up"]:
         try:
             from_file("tcov_" + t, f"{REF}/Tcov/Matrix/{t}")

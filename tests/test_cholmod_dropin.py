@@ -68,7 +68,7 @@ def _demo_resid(A, X, B):
 
 
 @pytest.mark.parametrize("which", BOTH)
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c"])
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "demo_can24"])
 def test_demo_chain_residual(which, name):
     """analyze (the demo's default ordering strategy) -> factorize -> solve, forced supernodal, the demo's criterion"""
     g = load_golden(name)
