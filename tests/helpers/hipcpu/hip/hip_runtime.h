@@ -18,6 +18,8 @@
 #include <cstring>
 #include <thread>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 
 namespace hipcpu {
@@ -102,7 +104,48 @@ template <class F> void launch_serial(int64_t grid, unsigned block, F call)
         for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; lane = (int)(t & 63); call(); }
 }
 // any kernel: `block` host threads (a multiple of 64), each running its lane of workgroup 0, 1, 2, ... in turn
-// __shared__ arrays are function statics here: launches from several host threads (one per simulated rank) take turns
+// The lanes of a workgroup are host threads from a pool that lives as long as the process (creating 256 threads per
+// launch is what the emulated tests used to spend most of their time on).  One launch at a time: __shared__ arrays are
+// function statics here, so launches from several host threads (one per simulated rank) take turns.
+struct Pool {
+    std::mutex mu;
+    std::condition_variable go, finished;
+    uint64_t gen = 0;
+    unsigned want = 0, done = 0, nthreads = 0;
+    std::function<void(unsigned)> job;
+    void worker(unsigned t, uint64_t seen)
+    {
+        for (;;) {
+            std::function<void(unsigned)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                go.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (t >= want) continue;
+                f = job;
+            }
+            f(t);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (++done == want) finished.notify_all();
+            }
+        }
+    }
+    void run(unsigned n, std::function<void(unsigned)> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        while (nthreads < n) {
+            const unsigned t = nthreads++;
+            const uint64_t seen = gen;
+            std::thread([this, t, seen] { worker(t, seen); }).detach();
+        }
+        job = std::move(f); want = n; done = 0; gen++;
+        go.notify_all();
+        finished.wait(lk, [&] { return done == want; });
+        job = nullptr;
+    }
+};
+inline Pool &pool() { static Pool *p = new Pool; return *p; }   // never destroyed: its threads outlive main()
 inline std::mutex launch_mu;
 template <class F> void launch(int64_t grid, unsigned block, F call, unsigned grid_y = 1)
 {
@@ -111,20 +154,17 @@ template <class F> void launch(int64_t grid, unsigned block, F call, unsigned gr
     const unsigned nw = block / 64;
     pthread_barrier_init(&B.bar, nullptr, block);
     for (unsigned w = 0; w < nw; w++) pthread_barrier_init(&B.wave[w].bar, nullptr, 64);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < block; t++)
-        th.emplace_back([&, t] {
-            blk = &B; wav = &B.wave[t / 64]; lane = (int)(t & 63);
-            blockDim.x = block; gridDim.x = (unsigned)grid; gridDim.y = grid_y; threadIdx.x = t;
-            for (unsigned by = 0; by < grid_y; by++)
-                for (int64_t b = 0; b < grid; b++) {
-                    blockIdx.x = (unsigned)b; blockIdx.y = by;
-                    call();
-                    pthread_barrier_wait(&B.bar);   // the next workgroup reuses the __shared__ statics
-                }
-            blockIdx.y = 0;
-        });
-    for (auto &t : th) t.join();
+    pool().run(block, [&](unsigned t) {
+        blk = &B; wav = &B.wave[t / 64]; lane = (int)(t & 63);
+        blockDim.x = block; gridDim.x = (unsigned)grid; gridDim.y = grid_y; threadIdx.x = t;
+        for (unsigned by = 0; by < grid_y; by++)
+            for (int64_t b = 0; b < grid; b++) {
+                blockIdx.x = (unsigned)b; blockIdx.y = by;
+                call();
+                pthread_barrier_wait(&B.bar);   // the next workgroup reuses the __shared__ statics
+            }
+        blockIdx.y = 0;
+    });
     pthread_barrier_destroy(&B.bar);
     for (unsigned w = 0; w < nw; w++) pthread_barrier_destroy(&B.wave[w].bar);
 }

@@ -121,7 +121,7 @@ def check_own_columns(g, owner, rank, Lx, Lo, tol=1e-10):
 
 @pytest.mark.parametrize("kind,size,world,dist_top,spoil,ob", [
     ("lap3d", 6, 3, True, False, 64), ("lap3d", 4, 2, True, True, 64), ("lap3d", 5, 2, False, False, 256),
-    ("lap2d", 16, 4, True, False, 64), ("helm", 4, 2, True, False, 64), ("lap2d", 8, 2, False, True, 256),
+    ("lap2d", 16, 4, True, False, 64), ("helm", 4, 2, True, False, 64),
     ("elast", 3, 3, True, False, 64)])
 def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob):
     from oracle import port
@@ -304,7 +304,7 @@ symbolic._ready = False
 from test_multigpu import problem
 from test_multi_abi import host_view, check_own_columns
 from oracle import port
-g = dict(problem("lap3d", 6))
+g = dict(problem("lap3d", 5))
 engine.set_tuning(2, 64); engine.set_tuning(7, 64)
 view = lambda p, n: torch.from_numpy(host_view(p, n))
 def amin(v):
