@@ -159,7 +159,9 @@ int mi355_factor_numeric_phase(mi355_factor *handle, int phase, double beta_re,
  *   mi355_factor_top_plan: the broadcasts, in the order every rank issues them -- `count` rows of 4 int64
  *     (step, lo, n, root): entries Lx[lo, lo+n) of mi355_factor_device_Lx from rank `root`; and the range
  *     [dinv_lo, dinv_hi) of block inverses (entries of mi355_factor_device_Dinv) to SUM over the ranks after
- *     the last segment, for the solves.  plan may be NULL to ask for count only.
+ *     the last segment, for the solves.  plan may be NULL to ask for count only.  `step` is where a broadcast is
+ *     ISSUED; the launches right behind it need not wait for it (tuning key 16) -- mi355_factor_numeric_multi knows the
+ *     wait points, a caller of this plan may simply wait at once.
  *   mi355_factor_top_run(h, seg): the launches between broadcast seg-1 and broadcast seg (seg = 0 .. count;
  *     returns when they have finished).  seg = count also reports the first failed pivot like numeric_phase.
  * Per factorization: numeric_phase(0); all-reduce the top panels; for seg in 0..count-1: top_run(seg),
@@ -202,9 +204,10 @@ int mi355_partition(int64_t n, int64_t nsuper, const int64_t *Super, const int64
 int mi355_factor_partition(mi355_factor *handle, int rank, int world, int min_subtrees_per_rank,
                            int distribute_top);
 
-/* what mi355_factor_partition decided: owner[nsuper] (may be NULL) and counts[8] (may be NULL): world, rank, blocks of
+/* what mi355_factor_partition decided: owner[nsuper] (may be NULL) and counts[10] (may be NULL): world, rank, blocks of
  * the distributed top (= broadcasts = reductions), merged top ranges, reductions planned, own-subtree steps enqueued
- * before the first / before the last reduction may start, own-subtree steps in all. */
+ * before the first / before the last reduction may start, own-subtree steps in all, broadcasts of THIS rank's schedule
+ * with launches between their issue and their wait point (look-ahead, tuning key 16), those launches in all. */
 int mi355_factor_partition_info(mi355_factor *handle, int32_t *owner, int64_t *counts);
 
 /* The collectives.  Either RCCL over xGMI -- stream-ordered: the engine's compute stream and the communicator's own
@@ -224,7 +227,11 @@ typedef struct {
     int (*bcast)(void *ctx, double *dev, int64_t count, int root);
     int (*allreduce_sum)(void *ctx, double *dev, int64_t count);
     int (*allreduce_min_i64)(void *ctx, int64_t *host_value);                 /* one value, on the host */
+    int flags;      /* MI355_TRANSPORT_DEFER: the engine queues reduce / bcast / allreduce calls and makes them at the next
+                     * point where it waits for them -- the LATEST completion its ordering allows (a plain blocking
+                     * transport shows the earliest); a testing aid for the ordering of communication and compute */
 } mi355_transport;
+#define MI355_TRANSPORT_DEFER 1
 int mi355_comm_create(const mi355_transport *t, mi355_comm **comm);
 int mi355_rccl_unique_id(void *id128);
 int mi355_comm_create_rccl(const void *id128, int rank, int world, int device, mi355_comm **comm);
@@ -344,7 +351,9 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * a second stream, measured +1.6 % at 150^3, off by default); key 14: update tasks of at most one 64 x 64 tile with
  * M*N*K <= value run one wave per task (k_gemm_tiny) instead of one workgroup per task (0 = off, the default: not
  * measured on the device yet); key 15: forward MFMA solve updates walk step tiles / value table entries per
- * workgroup (default 4096); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * workgroup (default 4096); key 16: look-ahead in the distributed top (default 1: of a finished block's trailing update only
+ * the part that targets the NEXT block runs before that block's panel chain, the rest after the chain's broadcast has been
+ * issued, so chain and broadcast overlap it; 0: the whole update first); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -73,6 +73,10 @@ struct mi355_comm_s {
     size_t ev_next = 0;
     int64_t *dkey = nullptr;            // one int64 on the device (the agreement on the status)
     int grouped = 0;
+    // MI355_TRANSPORT_DEFER (blocking transport): collectives are queued and run at the next point where the engine
+    // waits for them -- the LATEST completion the ordering allows, where a plain blocking transport shows the earliest
+    struct Queued { int kind; double *p; int64_t count; int root; };
+    std::vector<Queued> queue;
 };
 
 namespace {
@@ -119,9 +123,24 @@ int fence_to_comm(mi355_factor_s *F, mi355_comm_s *c)
     return MI355_OK;
 }
 
+int run_queued(mi355_comm_s *c)
+{
+    for (const mi355_comm_s::Queued &q : c->queue) {
+        if (q.kind == 0) CB_TRY(c->t.reduce_sum(c->t.ctx, q.p, q.count, q.root), "reduce_sum");
+        else if (q.kind == 1) CB_TRY(c->t.bcast(c->t.ctx, q.p, q.count, q.root), "bcast");
+        else CB_TRY(c->t.allreduce_sum(c->t.ctx, q.p, q.count), "allreduce_sum");
+    }
+    c->queue.clear();
+    return MI355_OK;
+}
+
 // the next launches on the engine's stream come after the collectives enqueued so far
 int fence_to_compute(mi355_factor_s *F, mi355_comm_s *c)
 {
+    if (!c->stream_ordered && !c->queue.empty()) {
+        HIP_TRY(hipStreamSynchronize(F->stream));       // what was launched since the collectives were queued
+        return run_queued(c);
+    }
     if (c->stream_ordered) {
         hipEvent_t e;
         int rc = comm_event(c, &e);
@@ -146,6 +165,7 @@ int c_reduce(mi355_comm_s *c, double *p, int64_t count, int root)
 {
     if (count <= 0) return MI355_OK;
     if (c->stream_ordered) RCCL_TRY(rccl().Reduce(p, p, (size_t)count, RCCL_F64, RCCL_SUM, root, c->nccl, c->cs));
+    else if (c->t.flags & MI355_TRANSPORT_DEFER) c->queue.push_back({0, p, count, root});
     else CB_TRY(c->t.reduce_sum(c->t.ctx, p, count, root), "reduce_sum");
     return MI355_OK;
 }
@@ -153,6 +173,7 @@ int c_bcast(mi355_comm_s *c, double *p, int64_t count, int root)
 {
     if (count <= 0) return MI355_OK;
     if (c->stream_ordered) RCCL_TRY(rccl().Broadcast(p, p, (size_t)count, RCCL_F64, root, c->nccl, c->cs));
+    else if (c->t.flags & MI355_TRANSPORT_DEFER) c->queue.push_back({1, p, count, root});
     else CB_TRY(c->t.bcast(c->t.ctx, p, count, root), "bcast");
     return MI355_OK;
 }
@@ -160,6 +181,7 @@ int c_allreduce(mi355_comm_s *c, double *p, int64_t count)
 {
     if (count <= 0) return MI355_OK;
     if (c->stream_ordered) RCCL_TRY(rccl().AllReduce(p, p, (size_t)count, RCCL_F64, RCCL_SUM, c->nccl, c->cs));
+    else if (c->t.flags & MI355_TRANSPORT_DEFER) c->queue.push_back({2, p, count, -1});
     else CB_TRY(c->t.allreduce_sum(c->t.ctx, p, count), "allreduce_sum");
     return MI355_OK;
 }
@@ -172,6 +194,7 @@ int c_agree_min(mi355_comm_s *c, int64_t *key)
         HIP_TRY(hipMemcpyAsync(key, c->dkey, sizeof(int64_t), hipMemcpyDeviceToHost, c->cs));
         HIP_TRY(hipStreamSynchronize(c->cs));
     } else {
+        if (!c->queue.empty()) return fail(MI355_GPU_PROBLEM, "internal: collectives still queued at the agreement");
         CB_TRY(c->t.allreduce_min_i64(c->t.ctx, key), "allreduce_min_i64");
     }
     return MI355_OK;
@@ -462,6 +485,12 @@ int mi355_factor_partition_info(mi355_factor *F, int32_t *owner, int64_t *counts
         counts[5] = F->reduce_plan.empty() ? 0 : F->reduce_plan.front().ready_step;
         counts[6] = F->reduce_plan.empty() ? 0 : F->reduce_plan.back().ready_step;
         counts[7] = F->part_local ? (int64_t)F->part_local->sched.steps.size() : 0;
+        // look-ahead of the distributed top: broadcasts whose wait point lies behind their issue point, and the launches
+        // that run in between (summed over those broadcasts)
+        counts[8] = counts[9] = 0;
+        if (F->part_dist)
+            for (const BcastPoint &b : F->part_dist->sched.bcasts)
+                if (b.wait_step > b.step) { counts[8]++; counts[9] += b.wait_step - b.step; }
     }
     return MI355_OK;
 }
@@ -626,24 +655,35 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
             const int64_t lo = F->part_local->sched.dinv_size, hi = dsc.dinv_size;
             if (hi > lo) HIP_TRY(hipMemsetAsync(F->Dinv.p + lo * E, 0, (size_t)(hi - lo) * E * sizeof(double), F->stream));
         }
-        int64_t step0 = 0, k = 0;
-        while (k < nb) {
-            const int64_t step1 = dsc.bcasts[(size_t)k].step;
-            rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, step1);
+        // every broadcast has an issue point (its block is finished) and a wait point (the first launch that reads the
+        // block); between the two lie launches that do not need it (BcastPoint::wait_step: look-ahead)
+        int64_t step0 = 0, k = 0, wait_at = -1;
+        while (k < nb || wait_at >= 0) {
+            const int64_t issue_at = k < nb ? dsc.bcasts[(size_t)k].step : INT64_MAX;
+            if (wait_at >= 0 && wait_at <= issue_at) {
+                rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, wait_at);
+                if (rc) return rc;
+                step0 = wait_at;
+                wait_at = -1;
+                rc = fence_to_compute(F, c);            // everything issued so far has arrived
+                if (rc) return rc;
+                continue;
+            }
+            rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, issue_at);
             if (rc) return rc;
-            step0 = step1;
+            step0 = issue_at;
             rc = fence_to_comm(F, c);
             if (rc) return rc;
             rc = c_group_begin(c);
             if (rc) return rc;
-            for (; k < nb && dsc.bcasts[(size_t)k].step == step1; k++) {
+            for (; k < nb && dsc.bcasts[(size_t)k].step == issue_at; k++) {
                 const BcastPoint &b = dsc.bcasts[(size_t)k];
+                if (b.wait_step < b.step) { (void)c_group_end(c); return fail(MI355_GPU_PROBLEM, "internal: a broadcast is awaited before it is issued"); }
+                wait_at = wait_at < 0 ? b.wait_step : std::min(wait_at, b.wait_step);
                 rc = c_bcast(c, F->Lx.p + b.lo * E, b.count * E, b.root);
                 if (rc) { (void)c_group_end(c); return rc; }
             }
             rc = c_group_end(c);
-            if (rc) return rc;
-            rc = fence_to_compute(F, c);
             if (rc) return rc;
         }
         rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, (int64_t)dsc.steps.size());

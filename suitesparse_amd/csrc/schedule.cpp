@@ -359,10 +359,14 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 const int64_t K = e - b0, Nn = enc_end - e;
                 if (dist && lvl + 1 == W.size()) {
                     // outermost update, owner-computes: one task per target outer block, kept by its owner
+                    // look-ahead (Tuning::dist_lookahead): only the update of the NEXT block (c0 == e) feeds the next
+                    // panel chain; the updates of the blocks beyond it are launched after that chain's broadcast has
+                    // been issued (flattening below), so that chain and broadcast overlap them
                     for (int64_t c0 = e; c0 < ncol_eff; c0 += WB) {
                         const int64_t c1 = std::min<int64_t>(c0 + WB, ncol_eff);
                         if (owner(s, c0 / WB) != dist->rank) continue;
-                        L[lev].trail[it].push_back(make_gemm(
+                        auto &dst = (tuning().dist_lookahead && c0 > e) ? L[lev].rest[it] : L[lev].trail[it];
+                        dst.push_back(make_gemm(
                             psx + c0 + b0 * nsrow, psx + c0 + b0 * nsrow,
                             psx + c0 + c0 * nsrow, -1, nsrow, nsrow, nsrow,
                             nsrow - c0, c1 - c0, K, GEMM_DIRECT_SUB));
@@ -448,6 +452,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     // ---- flatten into launch order
     for (int lev = 0; lev < nlev; lev++) {
         LevelSteps &ls = L[lev];
+        std::vector<GemmTask> deferred;             // DistTop look-ahead: far updates waiting for the next broadcast point
         for (size_t it = 0; it < ls.potrf.size(); it++) {
             // assign Dinv slots for this step; the trsm task i pairs with the i-th potrf task
             // that has rows below it (same push order)
@@ -497,15 +502,29 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             out.potrf.insert(out.potrf.end(), pts.begin(), pts.end());
             if (st.count > 0) out.steps.push_back(st);
             flush_gemm(out, trs, lev, S, 1);
+            const size_t bp0 = out.bcasts.size();
             for (BcastPoint bp : ls.bcast[it]) {        // finished outer blocks, before anybody's update reads them
-                bp.step = (int64_t)out.steps.size();
+                bp.step = bp.wait_step = (int64_t)out.steps.size();
                 out.bcasts.push_back(bp);
+            }
+            if (dist) {
+                // the broadcasts of this iteration are issued here; the far updates of the PREVIOUS block end run next
+                // (they read blocks that arrived long ago), and only then must the new blocks have arrived
+                if (out.bcasts.size() > bp0 && !deferred.empty()) {
+                    flush_gemm(out, deferred, lev, S, 0, 0);
+                    deferred.clear();
+                }
+                for (size_t k = bp0; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
+                flush_gemm(out, ls.trail[it], lev, S, 0, 0);
+                deferred.insert(deferred.end(), ls.rest[it].begin(), ls.rest[it].end());
+                continue;
             }
             // an iteration that ends an outer block: its update of the next block waits for the previous far
             // part (same target columns), its own far part then goes to the side stream
             flush_gemm(out, ls.trail[it], lev, S, 0, ls.rest[it].empty() ? 0 : STEP_JOIN);
             flush_gemm(out, ls.rest[it], lev, S, 0, STEP_SIDE);
         }
+        if (!deferred.empty()) flush_gemm(out, deferred, lev, S, 0, 0);
         flush_gemm(out, ls.updates, lev, S, 0, STEP_JOIN);
     }
 }
@@ -697,6 +716,24 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         const BcastPoint &b = sc.bcasts[i];
         if (b.lo < 0 || b.count <= 0 || b.lo + b.count > xs || b.step < 0 || b.step > (int64_t)sc.steps.size() || b.root < 0)
             return bad("broadcast", (int64_t)i);
+        if (b.wait_step < b.step || b.wait_step > (int64_t)sc.steps.size()) return bad("broadcast wait point", (int64_t)i);
+        if (i > 0 && (b.step < sc.bcasts[i - 1].step || b.wait_step < sc.bcasts[i - 1].wait_step))
+            return bad("broadcast order", (int64_t)i);
+        // look-ahead: nothing launched between the issue and the wait point may touch the block in flight
+        for (int64_t si = b.step; si < b.wait_step; si++) {
+            const Step &st = sc.steps[(size_t)si];
+            if (st.kind != STEP_GEMM) return bad("broadcast in flight over a panel step", (int64_t)i);
+            for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                const GemmTask &t = sc.gemm[(size_t)ti];
+                auto hits = [&](int64_t off, int64_t rows, int64_t cols, int64_t ld) {
+                    return off < b.lo + b.count && last(off, rows, cols, ld) >= b.lo;
+                };
+                if (hits(t.a_off, t.M, t.K, t.lda)) return bad("broadcast in flight: A operand of a task", (int64_t)i);
+                if (t.mode != GEMM_OVERWRITE && hits(t.b_off, t.N, t.K, t.ldb)) return bad("broadcast in flight: B operand of a task", (int64_t)i);
+                if (t.mode == GEMM_SCATTER_SUB) return bad("broadcast in flight over a scatter update", (int64_t)i);
+                if (hits(t.c_off, t.M, t.N, t.ldc)) return bad("broadcast in flight: target of a task", (int64_t)i);
+            }
+        }
     }
     if (!ss) return "";
     for (size_t i = 0; i < ss->groups.size(); i++) {

@@ -144,7 +144,10 @@ struct Symbolic {
 // is then broadcast (BcastPoint) before anybody reads it.  The schedule of rank `rank` holds its tasks only.
 struct DistTop { int32_t rank = 0, world = 1; };
 struct BcastPoint {
-    int64_t step;       // the broadcast happens before steps[step] (after everything earlier)
+    int64_t step;       // the broadcast is ISSUED before steps[step] (after everything earlier: the block is finished)
+    int64_t wait_step;  // ... and must have ARRIVED before steps[wait_step] (>= step).  Between the two lie launches that
+                        // do not read the block: with Tuning::dist_lookahead the far part of the PREVIOUS block's
+                        // trailing update (its targets beyond the next block), so the broadcast travels while they run
     int64_t lo, count;  // entries of Lx: the block's columns, contiguous
     int32_t root;       // owner of the block
     int32_t s;          // supernode
@@ -210,7 +213,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; int dist_lookahead = 1; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

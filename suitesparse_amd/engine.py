@@ -53,7 +53,7 @@ _AMIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64))
 
 class _Transport(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("ctx", C.c_void_p), ("reduce_sum", _RED), ("bcast", _BC),
-                ("allreduce_sum", _AR), ("allreduce_min_i64", _AMIN)]
+                ("allreduce_sum", _AR), ("allreduce_min_i64", _AMIN), ("flags", C.c_int)]
 
 _LIB = None
 
@@ -185,9 +185,10 @@ class Comm:
         self._h, self.rank, self.world, self._keep = handle, rank, world, keep
 
     @classmethod
-    def custom(cls, rank, world, reduce_sum, bcast, allreduce_sum, allreduce_min):
+    def custom(cls, rank, world, reduce_sum, bcast, allreduce_sum, allreduce_min, defer=False):
         """blocking collectives of the caller's: reduce_sum(ptr, count, root), bcast(ptr, count, root),
-        allreduce_sum(ptr, count) on DEVICE pointers (counts in doubles), allreduce_min(value) -> value on the host"""
+        allreduce_sum(ptr, count) on DEVICE pointers (counts in doubles), allreduce_min(value) -> value on the host;
+        defer: MI355_TRANSPORT_DEFER (collectives made as late as the engine's ordering allows; a testing aid)"""
         def guard(fn):
             def run(*a):
                 try:
@@ -203,7 +204,7 @@ class Comm:
             p[0] = int(allreduce_min(int(p[0])))
         t = _Transport(int(rank), int(world), None,
                        _RED(guard(lambda _, p, n, r: reduce_sum(p, n, r))), _BC(guard(lambda _, p, n, r: bcast(p, n, r))),
-                       _AR(guard(lambda _, p, n: allreduce_sum(p, n))), _AMIN(guard(amin)))
+                       _AR(guard(lambda _, p, n: allreduce_sum(p, n))), _AMIN(guard(amin)), 1 if defer else 0)
         h = C.c_void_p()
         _check(lib().mi355_comm_create(C.byref(t), C.byref(h)))
         return cls(h, int(rank), int(world), keep=t)
@@ -535,10 +536,10 @@ class SupernodalFactor:
 
     def partition_info(self):
         owner = np.zeros(max(self.nsuper, 1), dtype=np.int32)
-        cnt = np.zeros(8, dtype=np.int64)
+        cnt = np.zeros(10, dtype=np.int64)
         _check(lib().mi355_factor_partition_info(self._h, owner.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         keys = ("world", "rank", "top_blocks", "top_ranges", "reductions", "steps_before_first_reduce",
-                "steps_before_last_reduce", "own_steps")
+                "steps_before_last_reduce", "own_steps", "lookahead_bcasts", "lookahead_launches")
         return owner[:self.nsuper], dict(zip(keys, cnt.tolist()))
 
     def numeric_multi(self, comm, beta=0.0, quick_return_if_not_posdef=False):

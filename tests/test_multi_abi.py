@@ -44,8 +44,9 @@ class Bus:
     """blocking collectives among the threads of one process, on host memory; a reduce leaves the other ranks'
     buffers as they are (partial sums), as a real one does"""
 
-    def __init__(self, world):
+    def __init__(self, world, defer=False):
         self.world = world
+        self.defer = defer          # MI355_TRANSPORT_DEFER: the engine makes the calls as late as its ordering allows
         self.bar = threading.Barrier(world, timeout=120)
         self.slot = [None] * world
         self.log = [[] for _ in range(world)]
@@ -83,7 +84,7 @@ class Bus:
             m = min(self.slot)
             self.bar.wait()
             return m
-        return engine.Comm.custom(rank, self.world, reduce_sum, bcast, allreduce_sum, allreduce_min)
+        return engine.Comm.custom(rank, self.world, reduce_sum, bcast, allreduce_sum, allreduce_min, defer=self.defer)
 
 
 def run_ranks(world, body):
@@ -119,11 +120,15 @@ def check_own_columns(g, owner, rank, Lx, Lo, tol=1e-10):
             assert relerr(got[low], want[low]) < tol, (rank, s)
 
 
-@pytest.mark.parametrize("kind,size,world,dist_top,spoil,ob", [
-    ("lap3d", 6, 3, True, False, 64), ("lap3d", 4, 2, True, True, 64), ("lap3d", 5, 2, False, False, 256),
-    ("lap2d", 16, 4, True, False, 64), ("helm", 4, 2, True, False, 64),
-    ("elast", 3, 3, True, False, 64)])
-def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob):
+@pytest.mark.parametrize("kind,size,world,dist_top,spoil,ob,defer,lookahead", [
+    ("lap3d", 6, 3, True, False, 64, True, 1), ("lap3d", 4, 2, True, True, 64, False, 1),
+    ("lap3d", 5, 2, False, False, 256, True, 1), ("lap2d", 16, 4, True, False, 64, False, 1),
+    ("helm", 4, 2, True, False, 64, True, 1), ("elast", 3, 3, True, False, 64, False, 0),
+    ("lap3d", 6, 2, True, False, 64, True, 0), ("lap3d", 10, 2, True, False, 64, True, 1)])
+def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob, defer, lookahead):
+    """defer: the transport completes every collective at the LATEST point the engine's ordering allows (a blocking one
+    shows the earliest) -- between the two, a broadcast or a reduction that is read too early or written too late
+    gives a wrong factor; lookahead: tuning key 16 (far trailing updates behind the next block's broadcast)"""
     from oracle import port
     from test_multigpu import problem
     g = dict(problem(kind, size))
@@ -135,8 +140,8 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
         g["Sx"] = Sx
     so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
     assert (so != 0) == spoil
-    engine.set_tuning(2, ob); engine.set_tuning(7, ob)
-    bus = Bus(world)
+    engine.set_tuning(2, ob); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
+    bus = Bus(world, defer)
     rng = np.random.default_rng(5)
     B = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if cplx else 0)
     want = None if spoil else port.super_solve(g, Lo, port.super_solve(g, Lo, B, lower=True), lower=False)
@@ -150,7 +155,7 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
             assert cnt["world"] == world and cnt["rank"] == rank
             assert (cnt["top_blocks"] > 0) == dist_top and cnt["reductions"] == cnt["top_blocks"]
             L.set_matrix(g["Sp"], g["Si"], g["Sx"])
-            for _ in range(2):                                  # a refactorization reuses everything
+            for _ in range(1 if size >= 10 else 2):             # a refactorization reuses everything
                 st = L.numeric_multi(comm, 0.0, False)
                 assert (st, L.minor) == (so, mo)
                 E = 2 if cplx else 1
@@ -170,31 +175,48 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
             L.close()
         run_ranks(world, body)
     finally:
-        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
+    if not lookahead:
+        assert all(i[1]["lookahead_bcasts"] == 0 for i in infos)
+    if (kind, size) == ("lap3d", 10):      # a top supernode of three or more blocks: the look-ahead really reorders launches
+        assert sum(i[1]["lookahead_bcasts"] for i in infos) > 0
     # every rank decided the same partition, and issued the same collectives in the same order
     for r in range(1, world):
         assert np.array_equal(infos[r][0], infos[0][0])
         assert bus.log[r] == bus.log[0]
     kinds = [k for k, _, _ in bus.log[0]]
     if dist_top and not spoil:
-        assert kinds.count("reduce") == 2 * infos[0][1]["top_blocks"] == kinds.count("bcast")
+        reps = 1 if size >= 10 else 2
+        assert kinds.count("reduce") == reps * infos[0][1]["top_blocks"] == kinds.count("bcast")
 
 
 def test_reductions_start_before_the_subtrees_are_done(engine):
     """the order of the reductions: a block of the top that only low levels of the subtrees update is summed while the
-    remaining levels are still to be enqueued (mi355_factor_partition_info counts[5..7])"""
+    remaining levels are still to be enqueued (mi355_factor_partition_info counts[5..7]); and the look-ahead of the
+    distributed top: with three or more blocks in a top supernode some broadcasts have launches between their issue
+    and their wait point (counts[8..9]), none with tuning key 16 off"""
     from test_multigpu import problem
-    g = dict(problem("lap3d", 9))
     engine.set_tuning(2, 64); engine.set_tuning(7, 64)
     try:
+        g = dict(problem("lap3d", 9))
         L = engine.SupernodalFactor(g)
         owner, cnt = L.partition(0, 4, 1, True)
         assert cnt["top_blocks"] > 0 and cnt["reductions"] == cnt["top_blocks"]
         assert cnt["steps_before_first_reduce"] <= cnt["steps_before_last_reduce"] <= cnt["own_steps"]
         assert cnt["steps_before_first_reduce"] < cnt["own_steps"]
         L.close()
+        g = dict(problem("lap3d", 12))
+        L = engine.SupernodalFactor(g)
+        owner, cnt = L.partition(0, 2, 1, True)
+        assert cnt["lookahead_bcasts"] > 0 and cnt["lookahead_launches"] >= cnt["lookahead_bcasts"]
+        L.close()
+        engine.set_tuning(16, 0)
+        L = engine.SupernodalFactor(g)
+        owner0, cnt0 = L.partition(0, 2, 1, True)
+        assert np.array_equal(owner0, owner) and cnt0["lookahead_bcasts"] == 0 and cnt0["top_blocks"] == cnt["top_blocks"]
+        L.close()
     finally:
-        engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
 
 
 def interleaved_forest():
