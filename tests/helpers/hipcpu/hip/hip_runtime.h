@@ -1,6 +1,6 @@
 // tests/helpers/hipcpu/hip/hip_runtime.h -- TEST INFRASTRUCTURE.
 // A stand-in for <hip/hip_runtime.h> that lets g++ compile the product's kernel sources
-// (suitesparse_amd/csrc/*.hip.hpp) UNCHANGED for execution on the CPU: one host thread per lane, 64 lanes per
+// (suitesparse_amd/csrc/*.hip.hpp) UNCHANGED for execution on the CPU: one fiber of the launching thread per lane, 64 lanes per
 // wave, blockDim.x / 64 waves per workgroup.  Only what those kernels use exists here:
 //   threadIdx / blockIdx / blockDim, __shared__ (a function-local static: workgroups run one after the other),
 //   __syncthreads (a barrier over the workgroup's threads), v_readlane / readfirstlane / __shfl / __shfl_xor and
@@ -13,6 +13,7 @@
 // Never part of the product; the emulator (tests/helpers/sched_emu.cpp) is its only user.
 #pragma once
 #include <pthread.h>
+#include <ucontext.h>
 #include <stdint.h>
 #include <cmath>
 #include <cstring>
@@ -24,20 +25,32 @@
 
 namespace hipcpu {
 struct Dim { unsigned x = 1, y = 1, z = 1; };
-struct Wave { pthread_barrier_t bar; int64_t slot[64]; double a[64], b[64]; };
-struct Block { pthread_barrier_t bar; Wave wave[16]; };
+// The lanes of a workgroup are FIBERS (ucontext) of the launching host thread, resumed round-robin: a barrier is a
+// counter and a generation number, a lane that waits yields to the next lane.  No kernel-level context switch and
+// no thread creation is involved, which is what made one-host-thread-per-lane slow (a 256-lane barrier cost 256
+// futex round trips on 8 cores).  Deterministic, too: the lanes always interleave in the same order.
+struct Barrier { unsigned n = 0, arrived = 0, gen = 0; };
+struct Wave { Barrier bar; int64_t slot[64]; double a[64], b[64]; };
+struct Block { Barrier bar; Wave wave[16]; };
 inline thread_local Dim threadIdx, blockIdx, blockDim, gridDim;
 inline thread_local Block *blk = nullptr;   // null: the thread-by-thread mode (kernels without any cross-lane operation)
 inline thread_local Wave *wav = nullptr;
 inline thread_local int lane = 0;
+inline void yield();                        // to the next lane of the launch (defined with the scheduler below)
+inline void barrier_wait(Barrier *b)
+{
+    const unsigned g = b->gen;
+    if (++b->arrived == b->n) { b->arrived = 0; b->gen = g + 1; return; }
+    while (b->gen == g) yield();
+}
 
-inline void syncthreads() { pthread_barrier_wait(&blk->bar); }
+inline void syncthreads() { barrier_wait(&blk->bar); }
 inline int64_t exchange(int64_t v, int src)
 {
     wav->slot[lane] = v;
-    pthread_barrier_wait(&wav->bar);
+    barrier_wait(&wav->bar);
     const int64_t r = wav->slot[src & 63];
-    pthread_barrier_wait(&wav->bar);
+    barrier_wait(&wav->bar);
     return r;
 }
 inline int readlane(int v, int src) { return (int)exchange(v, src); }
@@ -63,7 +76,7 @@ typedef double v4d_t __attribute__((vector_size(32)));
 inline v4d_t mfma_f64_16x16x4(double a, double b, v4d_t c)
 {
     wav->a[lane] = a; wav->b[lane] = b;
-    pthread_barrier_wait(&wav->bar);
+    barrier_wait(&wav->bar);
     const int j = lane & 15, l4 = lane >> 4;
     for (int r = 0; r < 4; r++) {
         const int i = l4 + 4 * r;
@@ -71,7 +84,7 @@ inline v4d_t mfma_f64_16x16x4(double a, double b, v4d_t c)
         for (int k = 0; k < 4; k++) s += wav->a[k * 16 + i] * wav->b[k * 16 + j];
         c[r] = s;
     }
-    pthread_barrier_wait(&wav->bar);
+    barrier_wait(&wav->bar);
     return c;
 }
 inline double unsafeAtomicAdd(double *p, double v)
@@ -103,70 +116,119 @@ template <class F> void launch_serial(int64_t grid, unsigned block, F call)
     for (int64_t b = 0; b < grid; b++)
         for (unsigned t = 0; t < block; t++) { blockIdx.x = (unsigned)b; threadIdx.x = t; lane = (int)(t & 63); call(); }
 }
-// any kernel: `block` host threads (a multiple of 64), each running its lane of workgroup 0, 1, 2, ... in turn
-// The lanes of a workgroup are host threads from a pool that lives as long as the process (creating 256 threads per
-// launch is what the emulated tests used to spend most of their time on).  One launch at a time: __shared__ arrays are
-// function statics here, so launches from several host threads (one per simulated rank) take turns.
-struct Pool {
-    std::mutex mu;
-    std::condition_variable go, finished;
-    uint64_t gen = 0;
-    unsigned want = 0, done = 0, nthreads = 0;
-    std::function<void(unsigned)> job;
-    void worker(unsigned t, uint64_t seen)
+// any kernel: `block` lanes (a multiple of 64) as fibers of the calling thread, each running its lane of workgroup
+// 0, 1, 2, ... in turn.  One launch at a time per process: __shared__ arrays are function statics here, so launches
+// from several host threads (one per simulated rank) take turns.
+#if defined(__x86_64__)
+// switch stacks: callee-saved registers pushed on the old stack, popped from the new one (System V x86-64); no system
+// call, unlike swapcontext, which saves and restores the signal mask on every switch
+extern "C" void hipcpu_switch(void **save_sp, void *new_sp);
+__asm__(".text\n.weak hipcpu_switch\n.type hipcpu_switch,@function\nhipcpu_switch:\n"
+        "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+        "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+        "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+        ".size hipcpu_switch, .-hipcpu_switch\n");
+struct Context {
+    void *sp = nullptr;
+    void prepare(char *stack, size_t size, void (*entry)())
     {
-        for (;;) {
-            std::function<void(unsigned)> f;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                go.wait(lk, [&] { return gen != seen; });
-                seen = gen;
-                if (t >= want) continue;
-                f = job;
-            }
-            f(t);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (++done == want) finished.notify_all();
-            }
-        }
-    }
-    void run(unsigned n, std::function<void(unsigned)> f)
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        while (nthreads < n) {
-            const unsigned t = nthreads++;
-            const uint64_t seen = gen;
-            std::thread([this, t, seen] { worker(t, seen); }).detach();
-        }
-        job = std::move(f); want = n; done = 0; gen++;
-        go.notify_all();
-        finished.wait(lk, [&] { return done == want; });
-        job = nullptr;
+        uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+        void **w = (void **)top;
+        *--w = nullptr;                 // where a caller's return address would be: entry() sees rsp = 8 mod 16
+        *--w = (void *)entry;           // popped by the ret of hipcpu_switch
+        for (int i = 0; i < 6; i++) *--w = nullptr;     // rbp rbx r12 r13 r14 r15
+        sp = w;
     }
 };
-inline Pool &pool() { static Pool *p = new Pool; return *p; }   // never destroyed: its threads outlive main()
+inline void switch_to(Context &from, Context &to) { hipcpu_switch(&from.sp, to.sp); }
+#else
+struct Context {
+    ucontext_t uc;
+    void prepare(char *stack, size_t size, void (*entry)())
+    {
+        getcontext(&uc);
+        uc.uc_stack.ss_sp = stack; uc.uc_stack.ss_size = size; uc.uc_link = nullptr;
+        makecontext(&uc, entry, 0);
+    }
+};
+inline void switch_to(Context &from, Context &to) { swapcontext(&from.uc, &to.uc); }
+#endif
+struct Fiber {
+    Context ctx;
+    char *stack = nullptr;
+    bool done = false;
+    // the lane's view of the "registers" every kernel reads
+    Dim tIdx, bIdx;
+    Wave *wv = nullptr;
+    int ln = 0;
+};
+struct Launch {
+    std::vector<Fiber> fibers;
+    Context home;
+    int cur = -1;
+    std::function<void()> body;
+};
+inline thread_local Launch *running = nullptr;
+inline void yield()
+{
+    Launch *L = running;
+    Fiber &f = L->fibers[(size_t)L->cur];
+    f.tIdx = threadIdx; f.bIdx = blockIdx; f.wv = wav; f.ln = lane;
+    switch_to(f.ctx, L->home);
+    threadIdx = f.tIdx; blockIdx = f.bIdx; wav = f.wv; lane = f.ln;
+}
+inline void fiber_main()
+{
+    Launch *L = running;
+    L->body();
+    L->fibers[(size_t)L->cur].done = true;
+    switch_to(L->fibers[(size_t)L->cur].ctx, L->home);              // never resumed
+    __builtin_trap();
+}
+inline std::vector<char *> &stack_cache() { static thread_local std::vector<char *> c; return c; }
 inline std::mutex launch_mu;
 template <class F> void launch(int64_t grid, unsigned block, F call, unsigned grid_y = 1)
 {
     std::lock_guard<std::mutex> one_at_a_time(launch_mu);
+    constexpr size_t STACK = 256 * 1024;
     Block B;
     const unsigned nw = block / 64;
-    pthread_barrier_init(&B.bar, nullptr, block);
-    for (unsigned w = 0; w < nw; w++) pthread_barrier_init(&B.wave[w].bar, nullptr, 64);
-    pool().run(block, [&](unsigned t) {
-        blk = &B; wav = &B.wave[t / 64]; lane = (int)(t & 63);
-        blockDim.x = block; gridDim.x = (unsigned)grid; gridDim.y = grid_y; threadIdx.x = t;
+    B.bar.n = block;
+    for (unsigned w = 0; w < nw; w++) B.wave[w].bar.n = 64;
+    Launch L;
+    L.fibers.resize(block);
+    std::vector<char *> &cache = stack_cache();
+    while (cache.size() < block) cache.push_back((char *)std::malloc(STACK));
+    blk = &B; blockDim.x = block; gridDim.x = (unsigned)grid; gridDim.y = grid_y;
+    L.body = [&] {
         for (unsigned by = 0; by < grid_y; by++)
             for (int64_t b = 0; b < grid; b++) {
                 blockIdx.x = (unsigned)b; blockIdx.y = by;
                 call();
-                pthread_barrier_wait(&B.bar);   // the next workgroup reuses the __shared__ statics
+                barrier_wait(&B.bar);   // the next workgroup reuses the __shared__ statics
             }
         blockIdx.y = 0;
-    });
-    pthread_barrier_destroy(&B.bar);
-    for (unsigned w = 0; w < nw; w++) pthread_barrier_destroy(&B.wave[w].bar);
+    };
+    for (unsigned t = 0; t < block; t++) {
+        Fiber &f = L.fibers[t];
+        f.stack = cache[t];
+        f.ctx.prepare(f.stack, STACK, fiber_main);
+        f.tIdx.x = t; f.wv = &B.wave[t / 64]; f.ln = (int)(t & 63);
+    }
+    Launch *outer = running;
+    running = &L;
+    unsigned left = block;
+    while (left > 0)
+        for (unsigned t = 0; t < block; t++) {
+            Fiber &f = L.fibers[t];
+            if (f.done) continue;
+            L.cur = (int)t;
+            threadIdx = f.tIdx; blockIdx = f.bIdx; wav = f.wv; lane = f.ln;
+            switch_to(L.home, f.ctx);
+            if (f.done) left--;
+        }
+    running = outer;
+    blk = nullptr; wav = nullptr;
 }
 }  // namespace hipcpu
 

@@ -13,7 +13,7 @@ using namespace mi355;
 
 // ---- the product's kernels, from their own source, on the CPU.  tests/helpers/hipcpu/hip/hip_runtime.h stands in for
 // the HIP header (the build puts it first on the include path), so kernels.hip.hpp compiles unchanged: kernels
-// without cross-lane operations run thread after thread (launch_serial), the others with one host thread per
+// without cross-lane operations run thread after thread (launch_serial), the others with one fiber per
 // lane (launch).  Emulator key 100: 1 = assembly, k_relmap, k_gemm_tiny; 2 = also k_potrf16; 3 = every kernel of
 // the real factorization (k_potrf64, k_trsm64, k_gemm64, k_gemm128) with the engine's launch geometry.
 #include "../../suitesparse_amd/csrc/kernels.hip.hpp"

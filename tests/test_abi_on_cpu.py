@@ -1,6 +1,6 @@
 """The GPU test bodies, on the CPU.  build() compiles the engine ITSELF -- engine.hip's host code and every kernel, the
 whole C ABI of include/mi355_cholmod.h -- for the host against tests/helpers/hipcpu/hip/hip_runtime.h (device memory =
-host memory, a launch = one host thread per lane) into tests/helpers/libmi355_cpuemu.so.  Here the Python binding is
+host memory, a launch = one fiber per lane) into tests/helpers/libmi355_cpuemu.so.  Here the Python binding is
 pointed at that library (from the test only: the product knows nothing of it and has no CPU path) and the bodies of
 the GPU tests run on small cases.  What this covers that the schedule emulator cannot: the engine's host logic --
 staging and validation, the launch sequences of run_schedule and solve_dev, the not-positive-definite protocol, the

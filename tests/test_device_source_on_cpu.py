@@ -168,7 +168,7 @@ def test_assemble_sources_symmetric_real_and_complex(name):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Every kernel of the real factorization from its own source (emulator key 100 = 3): k_potrf64, k_trsm64, k_gemm64,
-# k_gemm128 compiled by g++ against tests/helpers/hipcpu/hip/hip_runtime.h (one host thread per lane; __syncthreads,
+# k_gemm128 compiled by g++ against tests/helpers/hipcpu/hip/hip_runtime.h (one fiber per lane; __syncthreads,
 # v_readlane and v_mfma_f64_16x16x4_f64 as barriers around exchange arrays) and launched with the engine's geometry.
 # Slow (a 256-thread barrier per __syncthreads), so the cases are small -- but they are the MFMA / LDS kernels.
 

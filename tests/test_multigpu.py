@@ -534,7 +534,7 @@ from suitesparse_amd import multigpu
 from oracle import port
 g = tm.problem("lap3d", 6)
 f = tm.EmuFactor(g)
-f.E.emu_set_tuning(100, 3)              # every factor kernel from the product's own source (one host thread per lane)
+f.E.emu_set_tuning(100, 3)              # every factor kernel from the product's own source (one fiber per lane)
 run = multigpu.PartitionedFactor(f, g, rank, world, min_subtrees_per_rank=1)
 assert run.dist and run.reduce is not None
 st = run.numeric()
