@@ -31,7 +31,7 @@ def engine():
         symbolic._ready = False
 
 
-@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_r5lo",
+@pytest.mark.parametrize("name", ["demo_bcsstk01", "demo_bcsstk02", "demo_c", "demo_can24", "tcov_c30lo_singular", "tcov_r5lo",
                                   "tcov_z5up", "tcov_ex5lo"])
 def test_golden_factor_and_solve(engine, name):
     import test_gpu_parity as t
@@ -40,7 +40,8 @@ def test_golden_factor_and_solve(engine, name):
 
 def test_quick_return_if_not_posdef(engine):
     import test_gpu_parity as t
-    t.test_quick_return_if_not_posdef(engine, "elast27_4_npd100")
+    for name in ("elast27_4_npd100", "lap2d_16_npd0"):
+        t.test_quick_return_if_not_posdef(engine, name)
 
 
 def test_error_paths_and_empty_factor(engine):
@@ -116,8 +117,7 @@ def test_unsym_through_the_abi(engine):
     """mi355_factor_set_matrix_unsym + k_assemble_aat: every unsymmetric fixture (real, complex, beta), zomplex and
     unpacked inputs, the argument checks"""
     import test_unsym as tu
-    # the thread-emulated engine is slow: the smaller fixtures here, all of them under -m gpu
-    for name in ("tcov_5by50", "tcov_5by50_beta", "tcov_c10", "lp_afiro"):
+    for name in tu.unsym_names():
         tu.test_gpu_golden_unsym(engine, name)
     tu.test_gpu_unsym_zomplex_unpacked_and_errors(engine)
 

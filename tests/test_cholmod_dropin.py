@@ -28,8 +28,8 @@ BOTH = [pytest.param("cpu", id="cpu"), pytest.param("gpu", id="gpu", marks=pytes
 
 
 def cases(cpu, gpu_only=()):
-    """(which, name) pairs: the thread-emulated CPU build of the engine is slow, so the larger fixtures run on the
-    GPU only"""
+    """(which, name) pairs; gpu_only: fixtures that take the CPU build of the engine (an emulation, lane by lane) more
+    than a few seconds"""
     out = [pytest.param("cpu", n, id=f"{n}-cpu") for n in cpu]
     out += [pytest.param("gpu", n, id=f"{n}-gpu", marks=pytest.mark.gpu) for n in list(cpu) + list(gpu_only)]
     return out
@@ -93,8 +93,9 @@ def test_demo_chain_residual(which, name):
     r.close()
 
 
-@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "elast27_4_metis", "tcov_z30lo",
-                                               "tcov_c30up"], ["lap3d_8_metis", "helm3d_6_metis", "lap2d_16_metis"]))
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "demo_can24", "elast27_4_metis",
+                                               "tcov_z30lo", "tcov_c30up", "lap3d_8_metis", "helm3d_6_metis",
+                                               "lap2d_16_metis"]))
 def test_same_factor_as_unchanged_reference(which, name):
     """on the fixture's permutation the patched build must hand back the SAME cholmod_factor: structure bit-exact,
     L->x within 1e-10 of what the unchanged reference produced (fixture), solution of cholmod_l_solve likewise"""
@@ -123,8 +124,8 @@ def test_same_factor_as_unchanged_reference(which, name):
     r.close()
 
 
-@pytest.mark.parametrize("which,name", cases(["tcov_c30lo_singular", "elast27_4_npd100"],
-                                             ["lap3d_8_npd200", "lap2d_16_npd0"]))
+@pytest.mark.parametrize("which,name", cases(["tcov_c30lo_singular", "elast27_4_npd100", "lap3d_8_npd200",
+                                              "lap2d_16_npd0"]))
 def test_not_posdef_through_the_api(which, name):
     """a warning, not an error: Common->status = CHOLMOD_NOT_POSDEF, L->minor = the failing column, the columns
     before it as the reference leaves them, the rest zero (t_cholmod_super_numeric_worker.c:1084-1146)"""
@@ -144,7 +145,7 @@ def test_not_posdef_through_the_api(which, name):
     r.close()
 
 
-@pytest.mark.parametrize("which,name", cases(["demo_bcsstk02"], ["lap3d_8_metis"]))
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "lap3d_8_metis"]))
 def test_refactorize_reuses_the_device_image_and_teardown(which, name):
     """second cholmod_l_factorize on the same L: same handle, new values; cholmod_l_free_factor and
     cholmod_l_change_factor (supernodal -> simplicial) destroy the device image; the converted factor still solves"""
@@ -289,8 +290,8 @@ def _both_builds(which, g):
     return r, u
 
 
-@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "tcov_c30lo_singular"],
-                                             ["tcov_z30lo", "lap3d_8_metis", "lap2d_16_npd0"]))
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk01", "demo_bcsstk02", "demo_c", "demo_can24",
+                                              "tcov_c30lo_singular", "tcov_z30lo", "lap3d_8_metis", "lap2d_16_npd0"]))
 def test_raw_factor_expert_sequence(which, name):
     """The reference's own raw_factor test (CHOLMOD/Tcov/t_raw_factor.c:109-340) through the patched build: no
     ordering, alloc_factor -> etree -> postorder -> rowcolcounts -> super_symbolic -> super_numeric -> super_lsolve ->
