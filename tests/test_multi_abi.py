@@ -221,6 +221,63 @@ def test_reductions_start_before_the_subtrees_are_done(engine):
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
+    """random SPD structures (sparse graphs, chains, arrows, dense blocks) under a random permutation, 2-5 ranks, random
+    top mode, block width, look-ahead switch and transport (blocking = earliest, deferred = latest completion of every
+    collective), sometimes a negative pivot: every rank must end with the oracle's columns of L (or its truncated
+    factor, minor and status), and the partitioned solves with its solution"""
+    import test_fuzz_schedule as tf
+    from oracle import port
+    from suitesparse_amd import symbolic
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["sparse", "banded", "arrow", "blocks"][seed % 4]
+    n = int(rng.integers(150, 420))
+    world = int(rng.integers(2, 6))
+    dist_top, defer, lookahead = bool(rng.integers(0, 4)), bool(rng.integers(0, 2)), int(rng.integers(0, 3) > 0)
+    ob = int(rng.choice([64, 64, 128, 256]))
+    spoil = seed % 5 == 4
+    Ap, Ai, Ax = tf.random_spd(kind, n, seed)
+    g = symbolic.analyze(n, Ap, Ai, rng.permutation(n))
+    Sp, Si, Sx = symbolic.permute(g, Ap, Ai, Ax)
+    if spoil:
+        Sx = Sx.copy()
+        k = int(rng.integers(0, n))
+        assert Si[Sp[k]] == k
+        Sx[Sp[k]] = -abs(Sx[Sp[k]])
+    so, mo, Lo = port.super_numeric(g, Sp, Si, Sx)
+    assert (so != 0) == spoil
+    B = rng.standard_normal((n, 2))
+    want = None if spoil else port.super_solve(g, Lo, port.super_solve(g, Lo, B, lower=True), lower=False)
+    engine.set_tuning(2, min(ob, 256)); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
+    bus = Bus(world, defer)
+    try:
+        def body(rank):
+            L = engine.SupernodalFactor(g)
+            comm = bus.comm(engine, rank)
+            owner, cnt = L.partition(rank, world, 1, dist_top)
+            L.set_matrix(Sp, Si, Sx)
+            st = L.numeric_multi(comm, 0.0, False)
+            assert (st, L.minor) == (so, mo)
+            Lx = host_view(L.device_Lx_ptr(), g["xsize"])
+            if spoil:
+                assert np.array_equal(Lx == 0, Lo == 0) and relerr(Lx, Lo) < 1e-10
+            else:
+                check_own_columns(g, owner, rank, Lx, Lo)
+                X = np.array(B.T, order="C", copy=True)
+                Xf = X.reshape(-1)
+                L.solve_multi_dev(comm, True, Xf.ctypes.data, 2, n)
+                L.solve_multi_dev(comm, False, Xf.ctypes.data, 2, n)
+                assert relerr(X.T, want) < 1e-9
+            comm.close()
+            L.close()
+        run_ranks(world, body)
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
+    for r in range(1, world):
+        assert bus.log[r] == bus.log[0]
+
+
 def interleaved_forest():
     """thirteen one-column supernodes whose subtrees are NOT contiguous index ranges (an analysis without
     postordering): leaves 0..7, leaf i -> 8 + i % 4, the four middle nodes -> 12"""
