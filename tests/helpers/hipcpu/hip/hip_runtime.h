@@ -119,6 +119,15 @@ template <class F> void launch_serial(int64_t grid, unsigned block, F call)
 // any kernel: `block` lanes (a multiple of 64) as fibers of the calling thread, each running its lane of workgroup
 // 0, 1, 2, ... in turn.  One launch at a time per process: __shared__ arrays are function statics here, so launches
 // from several host threads (one per simulated rank) take turns.
+// AddressSanitizer must be told about every stack switch (tools/asan_cpuemu.sh builds the engine's CPU build with it:
+// an out-of-bounds access of a kernel to "device" memory, which is malloc'ed host memory here, is then reported)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPCPU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+#endif
+#endif
 #if defined(__x86_64__)
 // switch stacks: callee-saved registers pushed on the old stack, popped from the new one (System V x86-64); no system
 // call, unlike swapcontext, which saves and restores the signal mask on every switch
@@ -130,9 +139,11 @@ __asm__(".text\n.weak hipcpu_switch\n.type hipcpu_switch,@function\nhipcpu_switc
         ".size hipcpu_switch, .-hipcpu_switch\n");
 struct Context {
     void *sp = nullptr;
-    void prepare(char *stack, size_t size, void (*entry)())
+    void *fake = nullptr; const void *bottom = nullptr; size_t size = 0;       // AddressSanitizer's view of this stack
+    void prepare(char *stack, size_t sz, void (*entry)())
     {
-        uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+        bottom = stack; size = sz;
+        uintptr_t top = ((uintptr_t)stack + sz) & ~(uintptr_t)15;
         void **w = (void **)top;
         *--w = nullptr;                 // where a caller's return address would be: entry() sees rsp = 8 mod 16
         *--w = (void *)entry;           // popped by the ret of hipcpu_switch
@@ -140,19 +151,31 @@ struct Context {
         sp = w;
     }
 };
-inline void switch_to(Context &from, Context &to) { hipcpu_switch(&from.sp, to.sp); }
+inline void raw_switch(Context &from, Context &to) { hipcpu_switch(&from.sp, to.sp); }
 #else
 struct Context {
     ucontext_t uc;
-    void prepare(char *stack, size_t size, void (*entry)())
+    void *fake = nullptr; const void *bottom = nullptr; size_t size = 0;
+    void prepare(char *stack, size_t sz, void (*entry)())
     {
+        bottom = stack; size = sz;
         getcontext(&uc);
-        uc.uc_stack.ss_sp = stack; uc.uc_stack.ss_size = size; uc.uc_link = nullptr;
+        uc.uc_stack.ss_sp = stack; uc.uc_stack.ss_size = sz; uc.uc_link = nullptr;
         makecontext(&uc, entry, 0);
     }
 };
-inline void switch_to(Context &from, Context &to) { swapcontext(&from.uc, &to.uc); }
+inline void raw_switch(Context &from, Context &to) { swapcontext(&from.uc, &to.uc); }
 #endif
+inline void switch_to(Context &from, Context &to)
+{
+#ifdef HIPCPU_ASAN
+    __sanitizer_start_switch_fiber(&from.fake, to.bottom, to.size);
+    raw_switch(from, to);
+    __sanitizer_finish_switch_fiber(from.fake, nullptr, nullptr);      // back on `from`'s stack
+#else
+    raw_switch(from, to);
+#endif
+}
 struct Fiber {
     Context ctx;
     char *stack = nullptr;
@@ -180,9 +203,18 @@ inline void yield()
 inline void fiber_main()
 {
     Launch *L = running;
+#ifdef HIPCPU_ASAN
+    // first time on this stack: tell the sanitizer, and learn the bounds of the launching thread's stack from it
+    __sanitizer_finish_switch_fiber(nullptr, &L->home.bottom, &L->home.size);
+#endif
     L->body();
     L->fibers[(size_t)L->cur].done = true;
+#ifdef HIPCPU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, L->home.bottom, L->home.size);      // nullptr: this stack is finished
+    raw_switch(L->fibers[(size_t)L->cur].ctx, L->home);
+#else
     switch_to(L->fibers[(size_t)L->cur].ctx, L->home);              // never resumed
+#endif
     __builtin_trap();
 }
 inline std::vector<char *> &stack_cache() { static thread_local std::vector<char *> c; return c; }
