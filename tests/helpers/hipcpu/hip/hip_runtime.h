@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -249,9 +251,22 @@ template <class F> void launch(int64_t grid, unsigned block, F call, unsigned gr
     }
     Launch *outer = running;
     running = &L;
+    // HIPCPU_LANE_ORDER: the order in which the lanes are resumed in every round -- 0 (default) ascending, 1 descending,
+    // 2 a new random order every round.  A kernel that lacks a barrier between a write of one lane and a read of
+    // another gives different results under different orders (the real machine runs the waves in any order)
+    static const int order_mode = [] { const char *e = std::getenv("HIPCPU_LANE_ORDER"); return e ? std::atoi(e) : 0; }();
+    std::vector<unsigned> order(block);
+    for (unsigned t = 0; t < block; t++) order[t] = order_mode == 1 ? block - 1 - t : t;
+    static thread_local uint64_t rng_state = 0x9e3779b97f4a7c15ull;
     unsigned left = block;
-    while (left > 0)
-        for (unsigned t = 0; t < block; t++) {
+    while (left > 0) {
+        if (order_mode == 2)
+            for (unsigned t = block - 1; t > 0; t--) {
+                rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+                std::swap(order[t], order[(size_t)(rng_state % (t + 1))]);
+            }
+        for (unsigned oi = 0; oi < block; oi++) {
+            const unsigned t = order[oi];
             Fiber &f = L.fibers[t];
             if (f.done) continue;
             L.cur = (int)t;
@@ -259,6 +274,7 @@ template <class F> void launch(int64_t grid, unsigned block, F call, unsigned gr
             switch_to(L.home, f.ctx);
             if (f.done) left--;
         }
+    }
     running = outer;
     blk = nullptr; wav = nullptr;
 }
