@@ -249,6 +249,12 @@ int mi355_comm_free(mi355_comm *comm);
 int mi355_factor_numeric_multi(mi355_factor *handle, mi355_comm *comm, double beta_re,
                                int quick_return_if_not_posdef, int64_t *minor, int *status);
 
+/* After a successful mi355_factor_numeric_multi: every rank sends the columns of its subtrees to all others (one
+ * broadcast per run of consecutive supernodes of one owner), so that every rank holds ALL of L in HBM and
+ * mi355_factor_get_Lx returns the complete L->x that cholmod_factorize promises its caller.  Volume: the subtrees'
+ * part of the factor crosses xGMI once.  The solves on N ranks do not need it. */
+int mi355_factor_gather_multi(mi355_factor *handle, mi355_comm *comm);
+
 /* L x = b (lower != 0) or L^H x = b on the partitioned factor: X (device, n x nrhs entries, ld d) holds the same
  * right-hand sides on every rank on entry and the same solution on every rank on return; one sum of X over the ranks
  * per sweep is the only exchange. */

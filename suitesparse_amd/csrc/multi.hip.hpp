@@ -751,6 +751,38 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
     return MI355_OK;
 }
 
+int mi355_factor_gather_multi(mi355_factor *F, mi355_comm *c)
+{
+    g_err.clear();
+    int rc = check_multi(F, c);
+    if (rc) return rc;
+    if (c->world == 1) return MI355_OK;
+    if (!F->part_ok) return fail(MI355_INVALID, "no positive-definite partitioned factor is resident");
+    const Symbolic &S = F->sym;
+    const int E = F->E;
+    rc = fence_to_comm(F, c);
+    if (rc) return rc;
+    rc = c_group_begin(c);
+    if (rc) return rc;
+    // every maximal run of consecutive supernodes of one owner is one contiguous range of Lx
+    for (int64_t s = 0; s < S.nsuper;) {
+        const int32_t r = F->part_owner[(size_t)s];
+        int64_t e = s + 1;
+        while (e < S.nsuper && F->part_owner[(size_t)e] == r) e++;
+        if (r >= 0) {
+            rc = c_bcast(c, F->Lx.p + S.Lpx[s] * E, (S.Lpx[e] - S.Lpx[s]) * E, r);
+            if (rc) { (void)c_group_end(c); return rc; }
+        }
+        s = e;
+    }
+    rc = c_group_end(c);
+    if (rc) return rc;
+    rc = fence_to_compute(F, c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(F->stream));
+    return MI355_OK;
+}
+
 int mi355_super_solve_multi_dev(mi355_factor *F, mi355_comm *c, int lower, int64_t nrhs, double *X, int64_t d)
 {
     g_err.clear();

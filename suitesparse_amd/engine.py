@@ -41,7 +41,7 @@ EXPORTS = [
     "mi355_factor_set_matrix_unsym", "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
     "mi355_partition", "mi355_factor_partition", "mi355_factor_partition_info", "mi355_comm_create", "mi355_rccl_unique_id",
     "mi355_comm_create_rccl", "mi355_comm_adopt_rccl", "mi355_comm_free", "mi355_factor_numeric_multi",
-    "mi355_super_solve_multi_dev",
+    "mi355_super_solve_multi_dev", "mi355_factor_gather_multi",
 ]
 
 # mi355_transport (include/mi355_cholmod.h): blocking collectives of the caller's
@@ -125,6 +125,7 @@ def lib():
         L.mi355_factor_numeric_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int64),
                                                  C.POINTER(C.c_int)]
         L.mi355_super_solve_multi_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+        L.mi355_factor_gather_multi.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -548,6 +549,10 @@ class SupernodalFactor:
                                                 C.byref(minor), C.byref(status)))
         self.minor, self.status = int(minor.value), int(status.value)
         return self.status
+
+    def gather_multi(self, comm):
+        """every rank receives the other ranks' subtree columns: Lx() is then the whole factor everywhere"""
+        _check(lib().mi355_factor_gather_multi(self._h, comm._h))
 
     def solve_multi_dev(self, comm, lower, X_ptr, nrhs, d):
         _check(lib().mi355_super_solve_multi_dev(self._h, comm._h, int(bool(lower)), int(nrhs), C.c_void_p(int(X_ptr)),

@@ -269,6 +269,15 @@ def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
                 L.solve_multi_dev(comm, True, Xf.ctypes.data, 2, n)
                 L.solve_multi_dev(comm, False, Xf.ctypes.data, 2, n)
                 assert relerr(X.T, want) < 1e-9
+                # the whole factor on every rank, for a caller that promised its own caller a complete L->x
+                L.gather_multi(comm)
+                full = L.Lx()
+                for s in range(g["nsuper"]):
+                    a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                    nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                    got, ref = full[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                    low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+                    assert relerr(got[low], ref[low]) < 1e-10, (rank, s)
             comm.close()
             L.close()
         run_ranks(world, body)
