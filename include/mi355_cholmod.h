@@ -210,6 +210,11 @@ int mi355_factor_partition(mi355_factor *handle, int rank, int world, int min_su
  * with launches between their issue and their wait point (look-ahead, tuning key 16), those launches in all. */
 int mi355_factor_partition_info(mi355_factor *handle, int32_t *owner, int64_t *counts);
 
+/* The reductions of the top's blocks in the order every rank issues them: `count` rows of 4 int64 (ready, lo, n, root) --
+ * entries Lx[lo, lo+n) are summed into rank `root` once THIS rank has enqueued `ready` launches of its own-subtree
+ * schedule (mi355_factor_partition_info counts[7] in all).  Diagnostic; plan may be NULL to ask for count only. */
+int mi355_factor_reduce_plan(mi355_factor *handle, int64_t cap, int64_t *plan, int64_t *count);
+
 /* The collectives.  Either RCCL over xGMI -- stream-ordered: the engine's compute stream and the communicator's own
  * stream order each other with events, the host does not wait inside a factorization; librccl is bound at run time
  * (the copy the process already holds, else the system's), the engine has no link-time dependency on it --

@@ -495,6 +495,22 @@ int mi355_factor_partition_info(mi355_factor *F, int32_t *owner, int64_t *counts
     return MI355_OK;
 }
 
+int mi355_factor_reduce_plan(mi355_factor *F, int64_t cap, int64_t *plan, int64_t *count)
+{
+    g_err.clear();
+    if (!F || !count) return fail(MI355_INVALID, "null argument");
+    if (F->part_world < 1) return fail(MI355_INVALID, "mi355_factor_partition was not called");
+    *count = (int64_t)F->reduce_plan.size();
+    if (!plan) return MI355_OK;
+    if (cap < *count) return fail(MI355_INVALID, "plan buffer too small");
+    const Schedule &dsc = F->part_dist->sched;
+    for (size_t i = 0; i < F->reduce_plan.size(); i++) {
+        const BcastPoint &b = dsc.bcasts[(size_t)F->reduce_plan[i].k];
+        plan[4 * i] = F->reduce_plan[i].ready_step; plan[4 * i + 1] = b.lo; plan[4 * i + 2] = b.count; plan[4 * i + 3] = b.root;
+    }
+    return MI355_OK;
+}
+
 int mi355_comm_create(const mi355_transport *t, mi355_comm **out)
 {
     g_err.clear();

@@ -41,7 +41,7 @@ EXPORTS = [
     "mi355_factor_set_matrix_unsym", "mi355_factor_set_perm", "mi355_solve", "mi355_solve_dev", "mi355_solve_x", "mi355_solve_x_dev",
     "mi355_partition", "mi355_factor_partition", "mi355_factor_partition_info", "mi355_comm_create", "mi355_rccl_unique_id",
     "mi355_comm_create_rccl", "mi355_comm_adopt_rccl", "mi355_comm_free", "mi355_factor_numeric_multi",
-    "mi355_super_solve_multi_dev", "mi355_factor_gather_multi",
+    "mi355_super_solve_multi_dev", "mi355_factor_gather_multi", "mi355_factor_reduce_plan",
 ]
 
 # mi355_transport (include/mi355_cholmod.h): blocking collectives of the caller's
@@ -542,6 +542,17 @@ class SupernodalFactor:
         keys = ("world", "rank", "top_blocks", "top_ranges", "reductions", "steps_before_first_reduce",
                 "steps_before_last_reduce", "own_steps", "lookahead_bcasts", "lookahead_launches")
         return owner[:self.nsuper], dict(zip(keys, cnt.tolist()))
+
+    def reduce_plan(self):
+        """rows (ready_step, lo, n, root) of the reductions of the top's blocks, in issue order"""
+        f = lib().mi355_factor_reduce_plan
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+        cnt = C.c_int64(0)
+        _check(f(self._h, 0, None, C.byref(cnt)))
+        plan = np.zeros((cnt.value, 4), dtype=np.int64)
+        if cnt.value:
+            _check(f(self._h, cnt.value, plan.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return plan
 
     def numeric_multi(self, comm, beta=0.0, quick_return_if_not_posdef=False):
         minor, status = C.c_int64(0), C.c_int(0)

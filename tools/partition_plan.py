@@ -31,6 +31,16 @@ def main():
     a = [sym["n"], sym["nsuper"], sym["Super"], sym["Lpi"], sym["Lpx"], sym["Ls"], len(sym["Ls"]), sym["xsize"]]
     print(f"{kind} {grid}: n {sym['n']}  fl {sym['fl']:.4g}  xsize {sym['xsize']:.4g}")
     t1 = None
+    # a handle of the CPU build of the engine (test infrastructure; no numeric work is done with it): the real schedules,
+    # reduce plan and look-ahead counts of mi355_factor_partition
+    handle = None
+    try:
+        from suitesparse_amd import engine
+        engine.LIB_PATH, engine._LIB = os.path.join(ROOT, "tests", "helpers", "libmi355_cpuemu.so"), None
+        symbolic._ready = False
+        handle = engine.SupernodalFactor(sym)
+    except Exception as e:      # noqa: BLE001
+        print(f"(no CPU build of the engine: {e}; round-2 lines left out)")
     for world in (1, 2, 4, 8):
         part = multigpu.partition(sym, world)
         owner = part["owner"]
@@ -57,9 +67,27 @@ def main():
         print(f"N={world}: phase0 flops max/mean {R[:, 0].max() / max(R[:, 0].mean(), 1):.3f} ({R[:, 0].max():.3g})  "
               f"top share max/mean {R[:, 1].max() / max(R[:, 1].mean(), 1):.3f} ({R[:, 1].max():.3g} of {R[0, 2]:.3g})  "
               f"top chain {int(R[0, 4])} steps  bcasts {int(R[0, 5])} = {R[0, 6] * 8e-9:.1f} GB  reduced to owners {top_entries * 8e-9:.1f} GB")
-        print(f"      model: phase0 {ph0 * 1e3:.0f} + {chain0 * 1e3:.0f} ms, reduce {allred * 1e3:.0f} ms, top gemm {topw * 1e3:.0f} ms, "
+        print(f"      model (round 1 schedule, everything serial): phase0 {ph0 * 1e3:.0f} + {chain0 * 1e3:.0f} ms, reduce {allred * 1e3:.0f} ms, top gemm {topw * 1e3:.0f} ms, "
               f"top chain {chain1 * 1e3:.0f} ms, broadcasts {bcast * 1e3:.0f} ms -> {total * 1e3:.0f} ms"
               + (f"  speedup {t1 / total:.2f}, efficiency {t1 / total / world:.2f}" if world > 1 else ""))
+        if world > 1 and handle is not None:
+            # round 2 schedule: (i) the reductions are issued as soon as a rank's last contribution to a block is
+            # enqueued -- the part of the volume whose ready point lies before the end of the own-subtree schedule can
+            # hide behind the subtree work that follows it (steps weighted equally: a crude proxy for time);
+            # (ii) look-ahead in the top: per block, chain + max(broadcast, far update) instead of their sum
+            owner_, cnt = handle.partition(0, world, 2, True)
+            plan = handle.reduce_plan()
+            own = max(cnt["own_steps"], 1)
+            vol = plan[:, 2].astype(float)
+            hidden = float((vol * (1.0 - plan[:, 0] / own)).sum() / max(vol.sum(), 1.0))
+            red2 = max(0.0, allred - hidden * (ph0 + chain0))
+            top2 = chain1 + max(bcast, topw)
+            total2 = ph0 + chain0 + red2 + top2
+            print(f"      model (round 2 schedule): {cnt['reductions']} reductions, {100 * float(vol[plan[:, 0] == 0].sum() / max(vol.sum(), 1)):.0f} % of their volume "
+                  f"ready at once, {100 * float(vol[plan[:, 0] >= own].sum() / max(vol.sum(), 1)):.0f} % only after the last subtree step; reduce not hidden {red2 * 1e3:.0f} ms; "
+                  f"top with look-ahead ({cnt['lookahead_bcasts']} of {cnt['top_blocks']} broadcasts have launches behind them) {top2 * 1e3:.0f} ms "
+                  f"-> {total2 * 1e3:.0f} ms  speedup {t1 / total2:.2f}, efficiency {t1 / total2 / world:.2f}, "
+                  f"{sym['fl'] / total2 / world / 78.6e12 * 100:.0f} % of {world} x 78.6 TF")
 
 
 if __name__ == "__main__":
