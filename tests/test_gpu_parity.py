@@ -121,10 +121,15 @@ def test_two_supernodes_scatter_update(engine):
     assert relerr(L.Lx(), Lo) < TOL_L
 
 
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("kind,size,ordering", [("lap3d", 24, "metis"), ("lap2d", 150, "metis"),
-                                                ("elast", 10, "metis"), ("lap3d", 20, "amd")])
+                                                ("elast", 10, "metis"), ("lap3d", 20, "amd"), ("lap3d", 64, "metis"),
+                                                ("lap3d", 100, "metis")])
 def test_vs_live_reference(engine, kind, size, ordering, have_ref):
-    """mid-size problems (supernodes > 256 wide, ~12 levels): reference CPU worker in the same run"""
+    """mid-size problems (supernodes > 256 wide, ~12 levels) and two large ones -- 64^3 and 100^3 (n = 10^6, an 8 GB
+    factor, supernodes up to ~15 000 columns, fl 5.4e12: half a minute of the reference on the host cores) -- against
+    the reference CPU worker in the same run, on the REFERENCE's METIS ordering: the 1e-10 bar on L anchored on the
+    oracle at a size where thousands of descendants add into one ancestor with FP64 atomics in no fixed order"""
     if not have_ref:
         pytest.skip("oracle/_ref not available on this box")
     from oracle.refcholmod import RefCholmod
