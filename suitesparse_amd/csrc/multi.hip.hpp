@@ -503,6 +503,7 @@ int mi355_factor_reduce_plan(mi355_factor *F, int64_t cap, int64_t *plan, int64_
     *count = (int64_t)F->reduce_plan.size();
     if (!plan) return MI355_OK;
     if (cap < *count) return fail(MI355_INVALID, "plan buffer too small");
+    if (!F->part_dist) return MI355_OK;             // replicated top: no per-block reductions
     const Schedule &dsc = F->part_dist->sched;
     for (size_t i = 0; i < F->reduce_plan.size(); i++) {
         const BcastPoint &b = dsc.bcasts[(size_t)F->reduce_plan[i].k];
