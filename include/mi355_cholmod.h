@@ -204,10 +204,12 @@ int mi355_partition(int64_t n, int64_t nsuper, const int64_t *Super, const int64
 int mi355_factor_partition(mi355_factor *handle, int rank, int world, int min_subtrees_per_rank,
                            int distribute_top);
 
-/* what mi355_factor_partition decided: owner[nsuper] (may be NULL) and counts[10] (may be NULL): world, rank, blocks of
- * the distributed top (= broadcasts = reductions), merged top ranges, reductions planned, own-subtree steps enqueued
- * before the first / before the last reduction may start, own-subtree steps in all, broadcasts of THIS rank's schedule
- * with launches between their issue and their wait point (look-ahead, tuning key 16), those launches in all. */
+/* what mi355_factor_partition decided: owner[nsuper] (may be NULL) and counts[11] (may be NULL): world, rank, column
+ * ranges of the distributed top that travel on their own (= broadcasts = reductions: the blocks, or with tuning key 17
+ * their pieces), merged top ranges, reductions planned, own-subtree steps enqueued before the first / before the last
+ * reduction may start, own-subtree steps in all, broadcasts of THIS rank's schedule with launches between their issue
+ * and their wait point (look-ahead, tuning key 16; pieces, key 17), those launches in all, and how many of the ranges
+ * are pieces sent before their block was complete. */
 int mi355_factor_partition_info(mi355_factor *handle, int32_t *owner, int64_t *counts);
 
 /* The reductions of the top's blocks in the order every rank issues them: `count` rows of 4 int64 (ready, lo, n, root) --
@@ -364,7 +366,9 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * measured on the device yet); key 15: forward MFMA solve updates walk step tiles / value table entries per
  * workgroup (default 4096); key 16: look-ahead in the distributed top (default 1: of a finished block's trailing update only
  * the part that targets the NEXT block runs before that block's panel chain, the rest after the chain's broadcast has been
- * issued, so chain and broadcast overlap it; 0: the whole update first); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * issued, so chain and broadcast overlap it; 0: the whole update first); key 17: a block of the distributed top is
+ * broadcast in finished pieces of the first nested width (key 2: 256 columns) while its panel chain is still running
+ * (default 1; 0: in one piece when it is complete); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

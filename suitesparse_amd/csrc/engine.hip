@@ -1541,6 +1541,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 14) tuning().tiny_max = std::max(0, value);
     else if (key == 15) tuning().solve_fwd_div_mma = std::max(1, value);
     else if (key == 16) tuning().dist_lookahead = value ? 1 : 0;
+    else if (key == 17) tuning().dist_pieces = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

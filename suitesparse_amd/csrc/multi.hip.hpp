@@ -487,10 +487,13 @@ int mi355_factor_partition_info(mi355_factor *F, int32_t *owner, int64_t *counts
         counts[7] = F->part_local ? (int64_t)F->part_local->sched.steps.size() : 0;
         // look-ahead of the distributed top: broadcasts whose wait point lies behind their issue point, and the launches
         // that run in between (summed over those broadcasts)
-        counts[8] = counts[9] = 0;
+        // pieces: entries of the plan that are not the last of their 1024-column block (tuning key 17)
+        counts[8] = counts[9] = counts[10] = 0;
         if (F->part_dist)
-            for (const BcastPoint &b : F->part_dist->sched.bcasts)
+            for (const BcastPoint &b : F->part_dist->sched.bcasts) {
                 if (b.wait_step > b.step) { counts[8]++; counts[9] += b.wait_step - b.step; }
+                if (!b.last) counts[10]++;
+            }
     }
     return MI355_OK;
 }

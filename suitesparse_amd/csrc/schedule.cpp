@@ -335,13 +335,23 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             L[lev].potrf[it].push_back(pt);
             L[lev].mine[it].push_back(own ? 1 : 0);
             if (own) out.flops_panel += (double)nb * nb * nb / 3.0;
-            if (dist && e == std::min<int64_t>((j / WB) * WB + WB, ncol_eff)) {
-                // outer block (s, j / WB) is complete after this iteration's TRSM: its columns go to everybody
+            if (dist) {
+                // outer block (s, j / WB) is complete after this iteration's TRSM: its columns go to everybody.  With
+                // Tuning::dist_pieces they go in pieces of the first nested width (256 columns): a piece is final as
+                // soon as its own panels are done -- the rest of the block's chain only touches later columns -- so it
+                // travels while the chain runs and only the last piece is left when the block is complete
                 const int64_t b0 = (j / WB) * WB;
-                BcastPoint bp;
-                bp.step = -1; bp.lo = psx + b0 * nsrow; bp.count = (e - b0) * nsrow;
-                bp.root = owner(s, j / WB); bp.s = (int32_t)s;
-                L[lev].bcast[it].push_back(bp);
+                const bool block_end = e == std::min<int64_t>(b0 + WB, ncol_eff);
+                const int64_t PW = (tuning().dist_pieces && W.size() > 1) ? W[1] : WB;
+                const int64_t p0 = std::max<int64_t>(b0, ((e - 1) / PW) * PW);
+                if (block_end || e == p0 + PW) {
+                    BcastPoint bp;
+                    bp.step = bp.wait_step = -1; bp.lo = psx + p0 * nsrow; bp.count = (e - p0) * nsrow;
+                    bp.root = owner(s, j / WB); bp.s = (int32_t)s;
+                    bp.mine = bp.root == dist->rank ? 1 : 0;
+                    bp.last = block_end ? 1 : 0;
+                    L[lev].bcast[it].push_back(bp);
+                }
             }
             if (below <= 0) continue;
             // X = B * inv(L11)^H  (trsm "R","L","C","N", worker :1175)
@@ -450,6 +460,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     }
 
     // ---- flatten into launch order
+    size_t awaited = 0;                             // DistTop: broadcasts [0, awaited) have their wait point
     for (int lev = 0; lev < nlev; lev++) {
         LevelSteps &ls = L[lev];
         std::vector<GemmTask> deferred;             // DistTop look-ahead: far updates waiting for the next broadcast point
@@ -502,19 +513,24 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             out.potrf.insert(out.potrf.end(), pts.begin(), pts.end());
             if (st.count > 0) out.steps.push_back(st);
             flush_gemm(out, trs, lev, S, 1);
-            const size_t bp0 = out.bcasts.size();
-            for (BcastPoint bp : ls.bcast[it]) {        // finished outer blocks, before anybody's update reads them
+            bool block_end = false;
+            for (BcastPoint bp : ls.bcast[it]) {        // finished blocks (or pieces), before anybody's update reads them
                 bp.step = bp.wait_step = (int64_t)out.steps.size();
+                block_end = block_end || bp.last;
                 out.bcasts.push_back(bp);
             }
             if (dist) {
-                // the broadcasts of this iteration are issued here; the far updates of the PREVIOUS block end run next
-                // (they read blocks that arrived long ago), and only then must the new blocks have arrived
-                if (out.bcasts.size() > bp0 && !deferred.empty()) {
-                    flush_gemm(out, deferred, lev, S, 0, 0);
-                    deferred.clear();
+                // the broadcasts of this iteration are issued here.  Where an outer block ends: the far updates of the
+                // PREVIOUS block end run next (they read blocks that arrived long ago), and only then must everything
+                // issued since -- this block's earlier pieces and its last one -- have arrived
+                if (block_end) {
+                    if (!deferred.empty()) {
+                        flush_gemm(out, deferred, lev, S, 0, 0);
+                        deferred.clear();
+                    }
+                    for (size_t k = awaited; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
+                    awaited = out.bcasts.size();
                 }
-                for (size_t k = bp0; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
                 flush_gemm(out, ls.trail[it], lev, S, 0, 0);
                 deferred.insert(deferred.end(), ls.rest[it].begin(), ls.rest[it].end());
                 continue;
@@ -525,6 +541,8 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             flush_gemm(out, ls.rest[it], lev, S, 0, STEP_SIDE);
         }
         if (!deferred.empty()) flush_gemm(out, deferred, lev, S, 0, 0);
+        for (size_t k = awaited; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
+        awaited = out.bcasts.size();
         flush_gemm(out, ls.updates, lev, S, 0, STEP_JOIN);
     }
 }
@@ -720,16 +738,23 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         if (i > 0 && (b.step < sc.bcasts[i - 1].step || b.wait_step < sc.bcasts[i - 1].wait_step))
             return bad("broadcast order", (int64_t)i);
         // look-ahead: nothing launched between the issue and the wait point may touch the block in flight
+        // (the rank that sends may go on reading the block; nobody may write it, and a receiver may not read it)
+        auto hits = [&](int64_t off, int64_t rows, int64_t cols, int64_t ld) {
+            return off < b.lo + b.count && last(off, rows, cols, ld) >= b.lo;
+        };
         for (int64_t si = b.step; si < b.wait_step; si++) {
             const Step &st = sc.steps[(size_t)si];
-            if (st.kind != STEP_GEMM) return bad("broadcast in flight over a panel step", (int64_t)i);
+            if (st.kind == STEP_POTRF) {
+                for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                    const PotrfTask &t = sc.potrf[(size_t)ti];
+                    if (hits(t.a_off, t.nb, t.nb, t.lda)) return bad("broadcast in flight: a diagonal block being factorized", (int64_t)i);
+                }
+                continue;
+            }
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const GemmTask &t = sc.gemm[(size_t)ti];
-                auto hits = [&](int64_t off, int64_t rows, int64_t cols, int64_t ld) {
-                    return off < b.lo + b.count && last(off, rows, cols, ld) >= b.lo;
-                };
-                if (hits(t.a_off, t.M, t.K, t.lda)) return bad("broadcast in flight: A operand of a task", (int64_t)i);
-                if (t.mode != GEMM_OVERWRITE && hits(t.b_off, t.N, t.K, t.ldb)) return bad("broadcast in flight: B operand of a task", (int64_t)i);
+                if (!b.mine && hits(t.a_off, t.M, t.K, t.lda)) return bad("broadcast in flight: A operand of a task", (int64_t)i);
+                if (!b.mine && t.mode != GEMM_OVERWRITE && hits(t.b_off, t.N, t.K, t.ldb)) return bad("broadcast in flight: B operand of a task", (int64_t)i);
                 if (t.mode == GEMM_SCATTER_SUB) return bad("broadcast in flight over a scatter update", (int64_t)i);
                 if (hits(t.c_off, t.M, t.N, t.ldc)) return bad("broadcast in flight: target of a task", (int64_t)i);
             }

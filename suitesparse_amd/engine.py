@@ -537,10 +537,10 @@ class SupernodalFactor:
 
     def partition_info(self):
         owner = np.zeros(max(self.nsuper, 1), dtype=np.int32)
-        cnt = np.zeros(10, dtype=np.int64)
+        cnt = np.zeros(11, dtype=np.int64)
         _check(lib().mi355_factor_partition_info(self._h, owner.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         keys = ("world", "rank", "top_blocks", "top_ranges", "reductions", "steps_before_first_reduce",
-                "steps_before_last_reduce", "own_steps", "lookahead_bcasts", "lookahead_launches")
+                "steps_before_last_reduce", "own_steps", "lookahead_bcasts", "lookahead_launches", "top_pieces")
         return owner[:self.nsuper], dict(zip(keys, cnt.tolist()))
 
     def reduce_plan(self):

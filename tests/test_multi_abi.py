@@ -126,7 +126,11 @@ def check_own_columns(g, owner, rank, Lx, Lo, tol=1e-10):
     ("helm", 4, 2, True, False, 64, True, 1), ("elast", 3, 3, True, False, 64, False, 0),
     ("lap3d", 6, 2, True, False, 64, True, 0), ("lap3d", 10, 2, True, False, 64, True, 1),
     ("lap3d", 12, 3, True, False, 64, True, 1), ("lap2d", 8, 2, False, True, 256, False, 1),
-    ("lap3d", 10, 2, True, True, 64, True, 1), ("helm", 8, 2, True, False, 64, True, 1)])
+    ("lap3d", 10, 2, True, True, 64, True, 1), ("helm", 8, 2, True, False, 64, True, 1),
+    # ob = (first nested width, block width): blocks of the top travel in pieces (tuning key 17) while their chain runs
+    ("lap3d", 12, 2, True, False, (128, 256), True, 1), ("lap3d", 14, 3, True, False, (128, 256), True, 1),
+    ("lap3d", 12, 2, True, False, (128, 256), False, 0), ("lap3d", 12, 3, True, True, (128, 256), True, 1),
+    ("helm", 10, 2, True, False, (128, 256), True, 1)])
 def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob, defer, lookahead):
     """defer: the transport completes every collective at the LATEST point the engine's ordering allows (a blocking one
     shows the earliest) -- between the two, a broadcast or a reduction that is read too early or written too late
@@ -142,7 +146,8 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
         g["Sx"] = Sx
     so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
     assert (so != 0) == spoil
-    engine.set_tuning(2, ob); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
+    ob1, ob2 = ob if isinstance(ob, tuple) else (ob, ob)
+    engine.set_tuning(2, ob1); engine.set_tuning(7, ob2); engine.set_tuning(16, lookahead)
     bus = Bus(world, defer)
     rng = np.random.default_rng(5)
     B = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if cplx else 0)
@@ -178,7 +183,7 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
         run_ranks(world, body)
     finally:
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
-    if not lookahead:
+    if not lookahead and not isinstance(ob, tuple):
         assert all(i[1]["lookahead_bcasts"] == 0 for i in infos)
     if kind == "lap3d" and size >= 10:      # a top supernode of three or more blocks: the look-ahead really reorders launches
         assert sum(i[1]["lookahead_bcasts"] for i in infos) > 0
@@ -190,6 +195,9 @@ def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world
     if dist_top and not spoil:
         reps = 1 if size >= 10 else 2
         assert kinds.count("reduce") == reps * infos[0][1]["top_blocks"] == kinds.count("bcast")
+    if isinstance(ob, tuple):
+        # pieces: a piece that is not the last of its block is issued with chain launches between it and its wait point
+        assert infos[0][1]["top_pieces"] > 0
 
 
 def test_reductions_start_before_the_subtrees_are_done(engine):
@@ -221,6 +229,83 @@ def test_reductions_start_before_the_subtrees_are_done(engine):
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1)
 
 
+def bordered(nleaf, wleaf, border, seed):
+    """block diagonal (nleaf dense blocks of wleaf columns) with `border` dense last rows: independent leaves under one
+    wide top supernode, in the natural order"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = nleaf * wleaf + border
+    M = sp.lil_matrix((n, n))
+    for b in range(nleaf):
+        M[b * wleaf:(b + 1) * wleaf, b * wleaf:(b + 1) * wleaf] = rng.standard_normal((wleaf, wleaf))
+    M[n - border:, :] = rng.standard_normal((border, n))
+    A = M.tocsr() + M.tocsr().T
+    d = np.asarray(abs(A).sum(axis=1)).ravel() + 1.0
+    Lw = sp.tril((A + sp.diags(d)).tocsc(), format="csc")
+    Lw.sort_indices()
+    return n, Lw.indptr.astype(np.int64), Lw.indices.astype(np.int64), np.ascontiguousarray(Lw.data)
+
+
+@pytest.mark.parametrize("world,defer,lookahead,pieces,spoil", [
+    (2, True, 1, 1, False), (3, False, 1, 1, False), (2, True, 0, 1, False), (4, True, 1, 1, False),
+    (2, True, 1, 0, False), (3, True, 1, 1, True)])
+def test_a_wide_top_supernode_travels_in_pieces(engine, world, defer, lookahead, pieces, spoil):
+    """a top supernode of 420 columns with blocks of 256 and a first nested width of 128: four ranges travel (columns
+    0-127 and 128-255 of block 0, 256-383 and 384-419 of block 1), the first of each block while its chain is still
+    running (tuning key 17); block 1 is updated by block 0 on its owner, so a piece that is read before it has
+    arrived, or overwritten while in flight, shows in L (deferred transport: latest completion)"""
+    from oracle import port
+    from suitesparse_amd import symbolic
+    n, Ap, Ai, Ax = bordered(8, 24, 420, 7)
+    g = symbolic.analyze(n, Ap, Ai, None)
+    Sp, Si, Sx = symbolic.permute(g, Ap, Ai, Ax)
+    widest = int(np.max(np.diff(g["Super"])))
+    assert widest >= 420
+    if spoil:
+        Sx = Sx.copy()
+        Sx[Sp[n - 100]] = -1.0
+    so, mo, Lo = port.super_numeric(g, Sp, Si, Sx)
+    assert (so != 0) == spoil
+    engine.set_tuning(2, 128); engine.set_tuning(7, 256); engine.set_tuning(16, lookahead); engine.set_tuning(17, pieces)
+    bus = Bus(world, defer)
+    infos = [None] * world
+    try:
+        def body(rank):
+            L = engine.SupernodalFactor(g)
+            comm = bus.comm(engine, rank)
+            owner, cnt = L.partition(rank, world, 1, True)
+            infos[rank] = cnt
+            L.set_matrix(Sp, Si, Sx)
+            for _ in range(2):
+                st = L.numeric_multi(comm, 0.0, False)
+                assert (st, L.minor) == (so, mo)
+                Lx = host_view(L.device_Lx_ptr(), g["xsize"])
+                if spoil:
+                    assert np.array_equal(Lx == 0, Lo == 0) and relerr(Lx, Lo) < 1e-10
+                else:
+                    check_own_columns(g, owner, rank, Lx, Lo)
+            if not spoil:
+                L.gather_multi(comm)
+                full = L.Lx()
+                for s in range(g["nsuper"]):
+                    a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                    nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                    got, ref = full[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                    low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+                    assert relerr(got[low], ref[low]) < 1e-10, (rank, s)
+            comm.close()
+            L.close()
+        run_ranks(world, body)
+    finally:
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(16, 1); engine.set_tuning(17, 1)
+    for r in range(1, world):
+        assert bus.log[r] == bus.log[0]
+    for cnt in infos:
+        assert cnt["top_pieces"] == (2 if pieces else 0) and cnt["top_blocks"] - cnt["top_pieces"] >= 2
+    if pieces:      # on the owner's schedule the chain's launches lie between a piece's issue and its wait point
+        assert sum(cnt["lookahead_bcasts"] for cnt in infos) >= 2
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
     """random SPD structures (sparse graphs, chains, arrows, dense blocks) under a random permutation, 2-5 ranks, random
@@ -236,6 +321,7 @@ def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
     world = int(rng.integers(2, 6))
     dist_top, defer, lookahead = bool(rng.integers(0, 4)), bool(rng.integers(0, 2)), int(rng.integers(0, 3) > 0)
     ob = int(rng.choice([64, 64, 128, 256]))
+    ob1 = 128 if ob == 256 and seed % 2 else min(ob, 256)      # (128, 256): the top's blocks travel in pieces (key 17)
     spoil = seed % 5 == 4
     Ap, Ai, Ax = tf.random_spd(kind, n, seed)
     g = symbolic.analyze(n, Ap, Ai, rng.permutation(n))
@@ -249,7 +335,7 @@ def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
     assert (so != 0) == spoil
     B = rng.standard_normal((n, 2))
     want = None if spoil else port.super_solve(g, Lo, port.super_solve(g, Lo, B, lower=True), lower=False)
-    engine.set_tuning(2, min(ob, 256)); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
+    engine.set_tuning(2, ob1); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
     bus = Bus(world, defer)
     try:
         def body(rank):

@@ -88,6 +88,11 @@ def main():
                   f"top with look-ahead ({cnt['lookahead_bcasts']} of {cnt['top_blocks']} broadcasts have launches behind them) {top2 * 1e3:.0f} ms "
                   f"-> {total2 * 1e3:.0f} ms  speedup {t1 / total2:.2f}, efficiency {t1 / total2 / world:.2f}, "
                   f"{sym['fl'] / total2 / world / 78.6e12 * 100:.0f} % of {world} x 78.6 TF")
+            # (iii) pieces (tuning key 17): what still has to travel when a block's chain ends is its last piece only; the
+            # chain -> broadcast -> update of the next block -> next chain path of the top carries that, not the whole block
+            tail = bcast * (cnt["top_blocks"] - cnt["top_pieces"]) / max(cnt["top_blocks"], 1)
+            print(f"      pieces: {cnt['top_pieces']} of {cnt['top_blocks']} ranges leave before their block is complete; broadcast left on the "
+                  f"chain -> broadcast -> next update path {bcast * 1e3:.0f} -> about {tail * 1e3:.0f} ms (equal-sized pieces assumed)")
 
 
 if __name__ == "__main__":
