@@ -1,4 +1,4 @@
-/* cholmod_mi355.h -- the CHOLMOD side of the drop-in: the four calls a CHOLMOD build adds to route its supernodal
+/* cholmod_mi355.h -- the CHOLMOD side of the drop-in: the calls a CHOLMOD build adds to route its supernodal
  * numeric factorization and supernodal triangular solves to libmi355_cholmod.so (include/mi355_cholmod.h).
  *
  * Implemented in suitesparse_amd/csrc/cholmod_mi355.c, which is compiled INTO CHOLMOD (it includes cholmod.h) with
@@ -35,6 +35,15 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
  * Returns TRUE if taken over (*ok = the return value), FALSE if L has no device image. */
 int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, cholmod_common *Common, int *ok) ;
 
+/* Inserted at the head of the supernodal branch of cholmod_l_solve2 (CHOLMOD/Cholesky/cholmod_solve.c:656-717: Y = P*B,
+ * cholmod_super_lsolve, cholmod_super_ltsolve, X = P'*Y): the whole branch on the device -- B goes down once, X comes
+ * back once, Y and E are not needed.  sys = CHOLMOD_A ... CHOLMOD_Lt; B real or complex under a real or complex L (a
+ * complex B under a real L is the reference's "dual" case, :668).  Returns TRUE if taken over (*ok = solve2's return
+ * value, X filled), FALSE if the host branch must run (no device image, zomplex B or X, L->minor < n) -- its two
+ * sweeps are then still taken over one by one by cholmod_mi355_super_solve. */
+int cholmod_mi355_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_dense *X, cholmod_common *Common,
+    int *ok) ;
+
 /* Inserted where a factor loses its supernodal arrays: cholmod_l_to_simplicial_sym
  * (CHOLMOD/Utility/t_cholmod_free_factor.c:22, reached from cholmod_l_free_factor and cholmod_l_change_factor) and
  * super_num_to_simplicial_num (CHOLMOD/Utility/t_cholmod_change_factor.c:1046).  Destroys the device image of L,
@@ -43,6 +52,10 @@ void cholmod_mi355_forget (cholmod_factor *L) ;
 
 /* number of factors that currently have a device image (tests: teardown really happens) */
 int cholmod_mi355_live_handles (void) ;
+
+/* calls taken over since the library was loaded: [0] cholmod_super_numeric, [1] single sweeps (cholmod_super_lsolve /
+ * _ltsolve), [2] whole cholmod_solve2 branches (tests: the device path, not a silent CPU one, produced a result) */
+void cholmod_mi355_calls_taken (int64_t out [3]) ;
 
 #ifdef __cplusplus
 }

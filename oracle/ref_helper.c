@@ -461,10 +461,52 @@ int ref_make_simplicial (void *hv, int to_ll)
 
 #ifdef REF_HELPER_MI355
 int cholmod_mi355_live_handles (void) ;
+void cholmod_mi355_calls_taken (int64_t out [3]) ;
 int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
+void ref_calls_taken (int64_t *out) { cholmod_mi355_calls_taken (out) ; }
 #else
 int ref_live_handles (void) { return -1 ; }
+void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = -1 ; }
 #endif
+
+// cholmod_l_solve2 (sys, L, B) with the caller-kept X / Y / E of cholmod_solve.c:119-153 (reused from call to call and
+// freed at the end of `reps` calls).  B: n x nrhs, leading dimension ldb, bxtype 1 real / 2 complex (interleaved) /
+// 3 zomplex (Bx then Bz); prefer_zomplex as Common->prefer_zomplex.  Xx receives X (n x nrhs, ld n; a zomplex X as
+// real part then imaginary part); *xxtype its xtype.
+int ref_solve2 (void *hv, int sys, int bxtype, int64_t nrhs, const double *Bx, const double *Bz, int64_t ldb,
+    int prefer_zomplex, int reps, double *Xx, int *xxtype)
+{
+    ref_ctx *h = hv ;
+    cholmod_factor *L = h->L ;
+    cholmod_dense B ;
+    memset (&B, 0, sizeof (B)) ;
+    B.nrow = L->n ; B.ncol = nrhs ; B.d = ldb ; B.nzmax = ldb * nrhs ;
+    B.x = (void *) Bx ; B.z = (void *) Bz ; B.xtype = bxtype ; B.dtype = CHOLMOD_DOUBLE ;
+    cholmod_dense *X = NULL, *Y = NULL, *E = NULL ;
+    const int save = h->cm.prefer_zomplex ;
+    h->cm.prefer_zomplex = prefer_zomplex ;
+    int ok = 1 ;
+    for (int r = 0 ; r < reps && ok ; r++)
+    {
+        ok = cholmod_l_solve2 (sys, L, &B, NULL, &X, NULL, &Y, &E, &h->cm) ;
+    }
+    h->cm.prefer_zomplex = save ;
+    if (ok && X)
+    {
+        const size_t cnt = L->n * nrhs ;
+        *xxtype = X->xtype ;
+        if (X->xtype == CHOLMOD_ZOMPLEX)
+        {
+            memcpy (Xx, X->x, cnt * sizeof (double)) ;
+            memcpy (Xx + cnt, X->z, cnt * sizeof (double)) ;
+        }
+        else memcpy (Xx, X->x, cnt * (X->xtype == CHOLMOD_COMPLEX ? 2 : 1) * sizeof (double)) ;
+    }
+    cholmod_l_free_dense (&X, &h->cm) ;
+    cholmod_l_free_dense (&Y, &h->cm) ;
+    cholmod_l_free_dense (&E, &h->cm) ;
+    return ok ? 0 : -1 ;
+}
 
 // Common-> options the reference's test_solver varies (CHOLMOD/Tcov/t_solve.c:61-124)
 int ref_set_option (void *hv, const char *name, double v)

@@ -135,6 +135,54 @@ class RefCholmod:
     def live_handles(self):
         return int(self.L.ref_live_handles())
 
+    def calls_taken(self):
+        """(numeric, single sweeps, whole solve2 branches) the drop-in took over since the library was loaded"""
+        out = np.zeros(3, dtype=np.int64)
+        self.L.ref_calls_taken.argtypes = [i64p]
+        self.L.ref_calls_taken(out)
+        return tuple(int(v) for v in out)
+
+    SYS = {"A": 0, "LDLt": 1, "LD": 2, "DLt": 3, "L": 4, "Lt": 5, "D": 6, "P": 7, "Pt": 8}
+
+    def solve2(self, sys, B, ldb=None, zomplex_b=False, prefer_zomplex=False, reps=1):
+        """cholmod_l_solve2 (sys, L, B) with reused X / Y / E workspaces; B is n x nrhs, real or complex (any
+        combination with L's xtype: cholmod_solve.c:228-235,668); ldb > n pads the columns of B; zomplex_b hands a
+        complex B over as separate real and imaginary arrays.  Returns X (n x nrhs)."""
+        B = np.asarray(B)
+        if B.ndim == 1:
+            B = B[:, None]
+        n, nrhs = B.shape
+        ldb = int(ldb or n)
+        cplx = np.iscomplexobj(B)
+        pad = np.full((ldb, nrhs), 7.5, dtype=B.dtype, order="F")      # the padding rows must not be read
+        pad[:n] = B
+        Bz = None
+        if cplx and zomplex_b:
+            Bx = np.ascontiguousarray(pad.real.T).reshape(-1)
+            Bz = np.ascontiguousarray(pad.imag.T).reshape(-1)
+            bxtype = 3
+        elif cplx:
+            Bx = np.ascontiguousarray(pad.T).view(np.float64).reshape(-1)
+            bxtype = 2
+        else:
+            Bx = np.ascontiguousarray(pad.T, dtype=np.float64).reshape(-1)
+            bxtype = 1
+        out = np.zeros(2 * n * nrhs)
+        xx = C.c_int(0)
+        f = self.L.ref_solve2
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, f64p, C.c_void_p, C.c_int64, C.c_int, C.c_int, f64p,
+                      C.POINTER(C.c_int)]
+        rc = f(self.h, self.SYS[sys] if isinstance(sys, str) else int(sys), bxtype, nrhs, Bx,
+               Bz.ctypes.data_as(C.c_void_p) if Bz is not None else None, ldb, int(bool(prefer_zomplex)), int(reps), out,
+               C.byref(xx))
+        if rc != 0:
+            raise RuntimeError("ref_solve2 failed")
+        if xx.value == 1:
+            return out[:n * nrhs].reshape(nrhs, n).T.copy()
+        if xx.value == 2:
+            return out.view(np.complex128).reshape(nrhs, n).T.copy()
+        return (out[:n * nrhs] + 1j * out[n * nrhs:]).reshape(nrhs, n).T.copy()
+
     def drop_factor(self):
         self.L.ref_drop_factor(self.h)
 

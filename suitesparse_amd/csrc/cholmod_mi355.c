@@ -11,6 +11,7 @@
 //   CHOLMOD/Supernodal/cholmod_super_numeric.c:100-335     wrapper whose worker switch (:295-322) is taken over
 //   CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:233  "Common->useGPU == 1 && L->useGPU" gate
 //   CHOLMOD/Supernodal/cholmod_super_solve.c:52-139,153-240  lsolve / ltsolve wrappers
+//   CHOLMOD/Cholesky/cholmod_solve.c:656-724                supernodal branch of cholmod_solve2 (Y = P*B, sweeps, X = P'*Y)
 //   CHOLMOD/Utility/t_cholmod_free_factor.c:22-90          where a factor loses its supernodal arrays
 //   CHOLMOD/GPU/t_cholmod_gpu.c:74-82                       error policy (report CHOLMOD_GPU_PROBLEM)
 //   CHOLMOD/Include/cholmod.h:966-986                       per-kernel time / call counters
@@ -41,11 +42,13 @@ typedef struct
     const void *super, *s ;         // the arrays the handle was built from
     size_t n, nsuper, ssize, xsize ;
     int lx ;                        // MI355_REAL / MI355_COMPLEX
+    int perm_set ;                  // L->Perm is on the device (cholmod_mi355_solve2)
 } entry_t ;
 
 static entry_t *table = NULL ;
 static int table_len = 0, table_cap = 0 ;
 static pthread_mutex_t table_lock = PTHREAD_MUTEX_INITIALIZER ;
+static int64_t taken [3] = {0, 0, 0} ;     // calls taken over: numeric, single sweeps, whole solve2 branches
 
 static int find_locked (const cholmod_factor *L)
 {
@@ -92,8 +95,37 @@ static int remember_handle (const cholmod_factor *L, mi355_factor *h, int lx)
     entry_t *e = &table [table_len++] ;
     e->L = L ; e->h = h ; e->super = L->super ; e->s = L->s ;
     e->n = L->n ; e->nsuper = L->nsuper ; e->ssize = L->ssize ; e->xsize = L->xsize ; e->lx = lx ;
+    e->perm_set = 0 ;
     pthread_mutex_unlock (&table_lock) ;
     return (1) ;
+}
+
+static int perm_flag (const cholmod_factor *L, int set)
+{
+    int was = 0 ;
+    pthread_mutex_lock (&table_lock) ;
+    int k = find_locked (L) ;
+    if (k >= 0)
+    {
+        was = table [k].perm_set ;
+        if (set) table [k].perm_set = 1 ;
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (was) ;
+}
+
+static void count_taken (int what)
+{
+    pthread_mutex_lock (&table_lock) ;
+    taken [what]++ ;
+    pthread_mutex_unlock (&table_lock) ;
+}
+
+void cholmod_mi355_calls_taken (int64_t out [3])
+{
+    pthread_mutex_lock (&table_lock) ;
+    for (int k = 0 ; k < 3 ; k++) out [k] = taken [k] ;
+    pthread_mutex_unlock (&table_lock) ;
 }
 
 void cholmod_mi355_forget (cholmod_factor *L)
@@ -228,6 +260,7 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
 #endif
         }
     }
+    count_taken (0) ;
     L->minor = (size_t) minor ;
     if (status == MI355_STATUS_NOT_POSDEF)
     {
@@ -254,6 +287,49 @@ int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, c
         *ok = FALSE ;
         return (TRUE) ;
     }
+    count_taken (1) ;
+    *ok = TRUE ;
+    return (TRUE) ;
+}
+
+// The whole supernodal branch of cholmod_solve2: B crosses to the device once, both permutations and both sweeps run
+// there, X comes back once (the two hooks above would move Y down and up once per sweep).
+int cholmod_mi355_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_dense *X, cholmod_common *Common,
+    int *ok)
+{
+    if (!L->is_super || L->dtype != CHOLMOD_DOUBLE || L->itype != CHOLMOD_LONG) return (FALSE) ;
+    if (B->dtype != CHOLMOD_DOUBLE || X->dtype != CHOLMOD_DOUBLE) return (FALSE) ;
+    if (L->xtype != CHOLMOD_REAL && L->xtype != CHOLMOD_COMPLEX) return (FALSE) ;
+    // zomplex right-hand sides and Common->prefer_zomplex results keep the host path (whose sweeps are still taken
+    // over one by one); D alone is a copy for an LL' factor
+    if (B->xtype != CHOLMOD_REAL && B->xtype != CHOLMOD_COMPLEX) return (FALSE) ;
+    const int cplx = (L->xtype == CHOLMOD_COMPLEX || B->xtype == CHOLMOD_COMPLEX) ;
+    if (X->xtype != (cplx ? CHOLMOD_COMPLEX : CHOLMOD_REAL)) return (FALSE) ;
+    if (sys < CHOLMOD_A || sys > CHOLMOD_Lt) return (FALSE) ;
+    if (L->minor < L->n) return (FALSE) ;
+    if (X->nrow != L->n || X->ncol != B->ncol || X->d < L->n) return (FALSE) ;
+    mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
+    if (h == NULL) return (FALSE) ;
+    int rc = MI355_OK ;
+    if (!perm_flag (L, 0))
+    {
+        // once per device image; the engine applies it for CHOLMOD_A only, as cholmod_solve.c:262-267 does
+        rc = mi355_factor_set_perm (h, L->ordering == CHOLMOD_NATURAL ? NULL : (const int64_t *) L->Perm) ;
+        if (rc == MI355_OK) (void) perm_flag (L, 1) ;
+    }
+    if (rc == MI355_OK)
+    {
+        rc = mi355_solve_x (h, sys, (int64_t) B->ncol, B->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX,
+                (const double *) B->x, (int64_t) B->d, (double *) X->x, (int64_t) X->d) ;
+    }
+    if (rc != MI355_OK)
+    {
+        if (rc == MI355_OUT_OF_MEMORY) cholmod_l_error (CHOLMOD_OUT_OF_MEMORY, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
+        else gpu_problem (Common, __FILE__, __LINE__) ;
+        *ok = FALSE ;
+        return (TRUE) ;
+    }
+    count_taken (2) ;
     *ok = TRUE ;
     return (TRUE) ;
 }

@@ -1,4 +1,4 @@
-"""The drop-in boundary compiled for real: the reference CHOLMOD with the five insertions of INTEGRATION.md section 2
+"""The drop-in boundary compiled for real: the reference CHOLMOD with the insertions of INTEGRATION.md section 2
 (oracle/apply_dispatch.py applies them to copies, oracle/build_ref_mi355.sh compiles them together with OUR glue
 suitesparse_amd/csrc/cholmod_mi355.c into oracle/_ref/libcholmod_mi355.so) running
 
@@ -88,8 +88,11 @@ def test_demo_chain_residual(which, name):
     for B in (np.ones((n, 1)), rng.standard_normal((n, 4))):
         if g["xtype"] == 2:
             B = B + 1j * rng.standard_normal(B.shape)
+        t0 = r.calls_taken()
         X = r.solve(B)
         assert _demo_resid(A, X, B) < 1e-7
+        t1 = r.calls_taken()
+        assert t1[2] - t0[2] == 1 and t1[1] == t0[1], (t0, t1)     # cholmod_l_solve: one trip to the device, not two
     r.close()
 
 
@@ -121,6 +124,56 @@ def test_same_factor_as_unchanged_reference(which, name):
     assert relerr(Y, g["Y"]) < 1e-10
     Z = r.super_solve(Y, lower=False)
     assert relerr(Z, g["Z"]) < 1e-10
+    r.close()
+
+
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "demo_c", "lap3d_8_metis", "helm3d_6_metis", "tcov_z30lo"]))
+def test_solve2_branch_on_the_device(which, name):
+    """cholmod_l_solve2's supernodal branch (cholmod_solve.c:656-717) taken over as a whole: B down once, P, both sweeps
+    and P' on the device, X back once -- for every system of an LL' factor, B real or complex under a real or complex
+    L (the reference's "dual" case), a padded B (d > n), reused X / Y / E handles; zomplex B or X and CHOLMOD_D keep
+    the host branch (whose sweeps are taken over one by one).  Expected values: dense algebra on P A P'."""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full(beta=g["beta"]) == 0
+    A = _dense_A(g) + g["beta"] * np.eye(n)
+    P = np.asarray(g["Perm"])
+    S = A[np.ix_(P, P)]
+    Ld = np.linalg.cholesky(S)
+    rng = np.random.default_rng(3)
+    Lcplx = g["xtype"] == 2
+    want = {"A": lambda B: np.linalg.solve(A, B), "LDLt": lambda B: np.linalg.solve(S, B),
+            "LD": lambda B: np.linalg.solve(Ld, B), "L": lambda B: np.linalg.solve(Ld, B),
+            "DLt": lambda B: np.linalg.solve(Ld.conj().T, B), "Lt": lambda B: np.linalg.solve(Ld.conj().T, B),
+            "D": lambda B: B}
+    for bc in (False, True):
+        for nrhs, ldb in ((1, n), (5, n + 3)):
+            B = rng.standard_normal((n, nrhs)) + (1j * rng.standard_normal((n, nrhs)) if bc else 0)
+            for sys in ("A", "LDLt", "LD", "DLt", "L", "Lt", "D"):
+                t0 = r.calls_taken()
+                X = r.solve2(sys, B, ldb=ldb, reps=2)
+                t1 = r.calls_taken()
+                assert np.iscomplexobj(X) == (bc or Lcplx)
+                assert relerr(X, want[sys](B)) < 1e-9, (sys, bc, nrhs)
+                if sys == "D":
+                    assert t1 == t0
+                else:
+                    assert t1[2] - t0[2] == 2 and t1[1] == t0[1], (sys, t0, t1)
+    # zomplex B, or a zomplex X asked for: the host branch, its sweeps on the device one at a time
+    B = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    for kw in (dict(zomplex_b=True), dict(prefer_zomplex=True)):
+        t0 = r.calls_taken()
+        X = r.solve2("A", B, **kw)
+        t1 = r.calls_taken()
+        assert relerr(X, np.linalg.solve(A, B)) < 1e-9
+        assert t1[2] == t0[2] and t1[1] - t0[1] == 2, (kw, t0, t1)
+    # after a refactorization the same device image (and its Perm) is used again
+    assert r.factorize_full(beta=g["beta"]) == 0
+    B = rng.standard_normal((n, 3))
+    assert relerr(r.solve2("A", B), np.linalg.solve(A, B)) < 1e-9
     r.close()
 
 
