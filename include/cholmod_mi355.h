@@ -30,6 +30,15 @@ void cholmod_mi355_select (cholmod_sparse *A, int for_whom, cholmod_factor *L, c
 int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2], cholmod_factor *L,
     cholmod_common *Common, int *ok) ;
 
+/* Inserted in cholmod_l_factorize_p before it builds S = tril (P*A*P') (CHOLMOD/Cholesky/cholmod_factorize.c:181-251;
+ * for a lower-stored A that is two cholmod_ptranspose calls, :228-238): TRUE = hand A itself to cholmod_super_numeric,
+ * the device places its entries through L->Perm (mi355_factor_set_matrix_perm) -- granted exactly when
+ * cholmod_mi355_super_numeric will take the call over (same gate), A is stored lower, real or complex, L is permuted,
+ * and nobody needs S afterwards (cholmod_resymbol_noperm, :275-282).  cholmod_mi355_defer_clear, inserted after the
+ * cholmod_super_numeric call, drops a grant the wrapper never consumed (it returned early on invalid input). */
+int cholmod_mi355_defer_permutation (cholmod_sparse *A, cholmod_factor *L, cholmod_common *Common) ;
+void cholmod_mi355_defer_clear (void) ;
+
 /* Inserted in cholmod_l_super_lsolve / _ltsolve before their worker switches
  * (CHOLMOD/Supernodal/cholmod_super_solve.c:114, :215): lower != 0 solves L x = b, else L' x = b, in X.
  * Returns TRUE if taken over (*ok = the return value), FALSE if L has no device image. */
@@ -54,8 +63,9 @@ void cholmod_mi355_forget (cholmod_factor *L) ;
 int cholmod_mi355_live_handles (void) ;
 
 /* calls taken over since the library was loaded: [0] cholmod_super_numeric, [1] single sweeps (cholmod_super_lsolve /
- * _ltsolve), [2] whole cholmod_solve2 branches (tests: the device path, not a silent CPU one, produced a result) */
-void cholmod_mi355_calls_taken (int64_t out [3]) ;
+ * _ltsolve), [2] whole cholmod_solve2 branches, [3] those of [0] that got A itself and placed it through L->Perm on the
+ * device (tests: the device path, not a silent CPU one, produced a result) */
+void cholmod_mi355_calls_taken (int64_t out [4]) ;
 
 #ifdef __cplusplus
 }

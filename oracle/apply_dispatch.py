@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """oracle/apply_dispatch.py -- TEST INFRASTRUCTURE.
 
-Applies the insertions of INTEGRATION.md section 2 to COPIES of six reference source files (the copies live under
+Applies the insertions of INTEGRATION.md section 2 to COPIES of seven reference source files (the copies live under
 oracle/_ref/patched/, git-ignored; nothing under /root/reference is touched and no reference text is kept in this
 repository: every insertion is located by a one-line anchor).  Insertions only -- no reference line is changed or
 removed -- and all of them sit under  #if defined (CHOLMOD_HAS_MI355) && defined (CHOLMOD_INT64).
@@ -49,6 +49,23 @@ EDITS = {
             "    " + GUARD,
             "    { int mi355_ok ; if (cholmod_mi355_super_solve (L, X, 0, Common, &mi355_ok)) return (mi355_ok) ; }",
             "    #endif",
+        ]),
+    ],
+    "Cholesky/cholmod_factorize.c": [
+        (r'^#include "cholmod_internal\.h"', 0, None),
+        (r"^\s*if \(L->ordering == CHOLMOD_NATURAL\)", 0, [    # supernodal branch of cholmod_factorize_p
+            "        " + GUARD,
+            "        if (cholmod_mi355_defer_permutation (A, L, Common))",
+            "        {",
+            "            S = A ;     /* the device places A through L->Perm: no permuted copy is built */",
+            "        }",
+            "        else",
+            "        #endif",
+        ]),
+        (r"^\s*status = Common->status ;", 0, [                 # right after the cholmod_super_numeric call
+            "        " + GUARD,
+            "        cholmod_mi355_defer_clear ( ) ;",
+            "        #endif",
         ]),
     ],
     "Cholesky/cholmod_solve.c": [

@@ -2,7 +2,7 @@
 # oracle/build_ref_mi355.sh -- TEST INFRASTRUCTURE, not product code.
 #
 # The reference CHOLMOD with the drop-in wired in, exactly as INTEGRATION.md describes it:
-#   * oracle/apply_dispatch.py inserts the hooks into COPIES of six reference sources (under
+#   * oracle/apply_dispatch.py inserts the hooks into COPIES of seven reference sources (under
 #     oracle/_ref/patched/, git-ignored; /root/reference is read only);
 #   * those copies are compiled with -DCHOLMOD_HAS_MI355 (and -DBLAS_TIMER, so that the Common->cholmod_gpu_*
 #     times are filled) together with OUR glue suitesparse_amd/csrc/cholmod_mi355.c;
@@ -39,7 +39,7 @@ INC="-I$ROOT/include -I$PATCHED/Supernodal -I$PATCHED/Utility -I$PATCHED/Cholesk
  -I$REF/CHOLMOD/SuiteSparse_metis/libmetis -I$REF/CHOLMOD/SuiteSparse_metis/include"
 CFLAGS="-O2 -fPIC -fopenmp -std=c11 -w -DBLAS32 -D_GNU_SOURCE -D_DEFAULT_SOURCE -DCHOLMOD_HAS_MI355 -DBLAS_TIMER"
 
-# the int64 AND int32 instantiations of the six files, compiled the way the reference's three-line wrappers
+# the int64 AND int32 instantiations of the seven files, compiled the way the reference's three-line wrappers
 # (cholmod_l_xxx.c: "#define CHOLMOD_INT64" + include) instantiate them -- the define goes on the command line, because
 # a quoted include from a wrapper under $REF would find the UNPATCHED file next to it first.  The int32 objects
 # compile the hooks away (CHOLMOD_INT64 is not defined there); they are rebuilt so that no object of the unchanged
@@ -54,6 +54,7 @@ build_pair Supernodal cholmod_super_symbolic.c super_symbolic ""
 build_pair Supernodal cholmod_super_numeric.c  super_numeric  ""
 build_pair Supernodal cholmod_super_solve.c    super_solve    ""
 build_pair Cholesky   cholmod_solve.c          solve          ""
+build_pair Cholesky   cholmod_factorize.c      factorize      ""
 build_pair Utility    t_cholmod_free_factor.c   free_factor   -DCHOLMOD_INT32
 build_pair Utility    t_cholmod_change_factor.c change_factor -DCHOLMOD_INT32
 gcc $CFLAGS -Wall $INC -c "$ROOT/suitesparse_amd/csrc/cholmod_mi355.c" -o "$POBJ/cholmod_mi355.o"

@@ -461,12 +461,12 @@ int ref_make_simplicial (void *hv, int to_ll)
 
 #ifdef REF_HELPER_MI355
 int cholmod_mi355_live_handles (void) ;
-void cholmod_mi355_calls_taken (int64_t out [3]) ;
+void cholmod_mi355_calls_taken (int64_t out [4]) ;
 int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
 void ref_calls_taken (int64_t *out) { cholmod_mi355_calls_taken (out) ; }
 #else
 int ref_live_handles (void) { return -1 ; }
-void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = -1 ; }
+void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = out [3] = -1 ; }
 #endif
 
 // cholmod_l_solve2 (sys, L, B) with the caller-kept X / Y / E of cholmod_solve.c:119-153 (reused from call to call and

@@ -136,8 +136,9 @@ class RefCholmod:
         return int(self.L.ref_live_handles())
 
     def calls_taken(self):
-        """(numeric, single sweeps, whole solve2 branches) the drop-in took over since the library was loaded"""
-        out = np.zeros(3, dtype=np.int64)
+        """(numeric, single sweeps, whole solve2 branches, numeric calls that got the unpermuted A) the drop-in took
+        over since the library was loaded"""
+        out = np.zeros(4, dtype=np.int64)
         self.L.ref_calls_taken.argtypes = [i64p]
         self.L.ref_calls_taken(out)
         return tuple(int(v) for v in out)

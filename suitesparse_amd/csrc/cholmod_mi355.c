@@ -12,6 +12,7 @@
 //   CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:233  "Common->useGPU == 1 && L->useGPU" gate
 //   CHOLMOD/Supernodal/cholmod_super_solve.c:52-139,153-240  lsolve / ltsolve wrappers
 //   CHOLMOD/Cholesky/cholmod_solve.c:656-724                supernodal branch of cholmod_solve2 (Y = P*B, sweeps, X = P'*Y)
+//   CHOLMOD/Cholesky/cholmod_factorize.c:181-262            S = tril (P*A*P') by two cholmod_ptranspose calls, then super_numeric
 //   CHOLMOD/Utility/t_cholmod_free_factor.c:22-90          where a factor loses its supernodal arrays
 //   CHOLMOD/GPU/t_cholmod_gpu.c:74-82                       error policy (report CHOLMOD_GPU_PROBLEM)
 //   CHOLMOD/Include/cholmod.h:966-986                       per-kernel time / call counters
@@ -48,7 +49,14 @@ typedef struct
 static entry_t *table = NULL ;
 static int table_len = 0, table_cap = 0 ;
 static pthread_mutex_t table_lock = PTHREAD_MUTEX_INITIALIZER ;
-static int64_t taken [3] = {0, 0, 0} ;     // calls taken over: numeric, single sweeps, whole solve2 branches
+static int64_t taken [4] = {0, 0, 0, 0} ;  // calls taken over: numeric, single sweeps, whole solve2 branches;
+                                            // [3]: numeric calls that placed A through L->Perm on the device
+
+// cholmod_factorize_p told us that the matrix it is about to hand to cholmod_super_numeric for this factor is A
+// ITSELF, not S = tril (P*A*P') (cholmod_mi355_defer_permutation).  Per thread: CHOLMOD is not re-entrant per Common,
+// distinct Commons may run on distinct threads.
+static __thread const cholmod_sparse *deferred_A = NULL ;
+static __thread const cholmod_factor *deferred_L = NULL ;
 
 static int find_locked (const cholmod_factor *L)
 {
@@ -121,10 +129,10 @@ static void count_taken (int what)
     pthread_mutex_unlock (&table_lock) ;
 }
 
-void cholmod_mi355_calls_taken (int64_t out [3])
+void cholmod_mi355_calls_taken (int64_t out [4])
 {
     pthread_mutex_lock (&table_lock) ;
-    for (int k = 0 ; k < 3 ; k++) out [k] = taken [k] ;
+    for (int k = 0 ; k < 4 ; k++) out [k] = taken [k] ;
     pthread_mutex_unlock (&table_lock) ;
 }
 
@@ -171,6 +179,36 @@ void cholmod_mi355_select (cholmod_sparse *A, int for_whom, cholmod_factor *L, c
 }
 
 // ---- numeric factorization -------------------------------------------------------------------------------------
+// the gate of t_cholmod_super_numeric_worker.c:233 ("Common->useGPU == 1 && L->useGPU") plus what this device path
+// covers: int64, double, stype <= 0
+static int numeric_gate (const cholmod_sparse *A, const cholmod_factor *L, const cholmod_common *Common)
+{
+    return (Common->useGPU == 1 && L->useGPU && A->dtype == CHOLMOD_DOUBLE && L->dtype == CHOLMOD_DOUBLE &&
+            L->itype == CHOLMOD_LONG && A->stype <= 0) ;
+}
+
+int cholmod_mi355_defer_permutation (cholmod_sparse *A, cholmod_factor *L, cholmod_common *Common)
+{
+    deferred_A = NULL ; deferred_L = NULL ;
+    // exactly the calls the numeric hook below will take over (else the CPU worker would meet an unpermuted matrix):
+    // a symbolic L gets A's dtype from the wrapper (cholmod_super_numeric.c:222), a numeric one must have it already
+    if (!(Common->useGPU == 1 && L->useGPU) || !L->is_super || L->itype != CHOLMOD_LONG) return (FALSE) ;
+    if (A->dtype != CHOLMOD_DOUBLE || (L->xtype != CHOLMOD_PATTERN && L->dtype != CHOLMOD_DOUBLE)) return (FALSE) ;
+    if (A->stype >= 0 || L->ordering == CHOLMOD_NATURAL || L->Perm == NULL) return (FALSE) ;
+    if (A->xtype != CHOLMOD_REAL && A->xtype != CHOLMOD_COMPLEX) return (FALSE) ;      // zomplex: the host copy
+    if (A->nrow != A->ncol || A->nrow != L->n) return (FALSE) ;
+    // cholmod_factorize_p hands S to cholmod_resymbol_noperm afterwards when it converts the result to a simplicial
+    // factor with final_resymbol (cholmod_factorize.c:275-282): it needs the permuted copy then
+    if (!Common->final_asis && Common->final_resymbol && !Common->final_super) return (FALSE) ;
+    deferred_A = A ; deferred_L = L ;
+    return (TRUE) ;
+}
+
+void cholmod_mi355_defer_clear (void)
+{
+    deferred_A = NULL ; deferred_L = NULL ;
+}
+
 static void gpu_problem (cholmod_common *Common, const char *file, int line)
 {
     cholmod_l_error (CHOLMOD_GPU_PROBLEM, file, line, mi355_last_error ( ), Common) ;
@@ -179,11 +217,20 @@ static void gpu_problem (cholmod_common *Common, const char *file, int line)
 int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2], cholmod_factor *L,
     cholmod_common *Common, int *ok)
 {
-    if (!(Common->useGPU == 1 && L->useGPU) || A->dtype != CHOLMOD_DOUBLE || L->dtype != CHOLMOD_DOUBLE ||
-        L->itype != CHOLMOD_LONG || A->stype > 0)
+    const int unpermuted = (deferred_A == A && deferred_L == L) ;
+    deferred_A = NULL ; deferred_L = NULL ;
+    if (!numeric_gate (A, L, Common))
     {
         // the CPU worker is about to rewrite L->x: a device image of L would be stale afterwards
         cholmod_mi355_forget (L) ;
+        if (unpermuted)
+        {
+            // cannot happen (cholmod_mi355_defer_permutation applies the same gate); never let the CPU worker
+            // factorize a matrix that was not permuted for it
+            cholmod_l_error (CHOLMOD_GPU_PROBLEM, __FILE__, __LINE__, "internal: unpermuted matrix at the CPU worker", Common) ;
+            *ok = FALSE ;
+            return (TRUE) ;
+        }
         return (FALSE) ;
     }
     // L is complex for a complex or zomplex A (cholmod_super_numeric.c:223-225)
@@ -219,6 +266,13 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
                     Anz, (const double *) A->x, zomplex ? (const double *) A->z : NULL,
                     (const int64_t *) F->p, (const int64_t *) F->i, F->packed ? NULL : (const int64_t *) F->nz,
                     (const double *) F->x, zomplex ? (const double *) F->z : NULL) ;
+        }
+        else if (unpermuted)
+        {
+            // A itself: the assembly kernel places A (i,j) at S (max, min) of the permuted indices, so the copy
+            // S = tril (P*A*P') of cholmod_factorize.c:228-238 is never built
+            rc = mi355_factor_set_matrix_perm (h, (const int64_t *) A->p, (const int64_t *) A->i, Anz,
+                    (const double *) A->x, (const int64_t *) L->Perm) ;
         }
         else if (zomplex)
         {
@@ -261,6 +315,7 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
         }
     }
     count_taken (0) ;
+    if (unpermuted) count_taken (3) ;
     L->minor = (size_t) minor ;
     if (status == MI355_STATUS_NOT_POSDEF)
     {

@@ -264,8 +264,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                 hipLaunchKernelGGL(cplx ? k_add_beta<2> : k_add_beta<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm, beta,
                                    F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->Lx.p, smask);
         } else if (F->A_perm) {
-            hipLaunchKernelGGL(cplx ? k_assemble_perm<2> : k_assemble_perm<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm,
-                               F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p, F->dIperm.p,
+            // every column of A is walked; ncols_asm limits the columns of S that receive entries
+            hipLaunchKernelGGL(cplx ? k_assemble_perm<2> : k_assemble_perm<1>, dim3((unsigned)((S.n + 255) / 256)), dim3(256), 0,
+                               F->stream, S.n, ncols_asm, F->Ap.p, F->Ai.p, F->A_unpacked ? F->Anz.p : (const int64_t *)nullptr, F->Ax.p, F->dIperm.p,
                                F->dSupermap.p, F->dSuper.p, F->dLpi.p, F->dLpx.p, F->dLs.p, F->Lx.p, smask);
             if (beta != 0.0)
                 hipLaunchKernelGGL(cplx ? k_add_beta<2> : k_add_beta<1>, dim3(grid), dim3(256), 0, F->stream, ncols_asm, beta,

@@ -77,11 +77,13 @@ __global__ __launch_bounds__(256) void k_assemble(
 // one thread per column of A -- the permuted copy S that cholmod_factorize builds with two ptransposes
 // (CHOLMOD/Cholesky/cholmod_factorize.c:225-236) never exists.  Entry A(i,j), i >= j, lands at
 // S(max(ki,kj), min(ki,kj)), ki = iperm[i], conjugated if the two swap; entries outside the pattern of L are
-// dropped (worker :462-467).  k_add_beta then adds beta to the diagonal (worker :510-520).
+// dropped (worker :462-467).  Only the columns kc < climit of S are assembled (the replay of a failed factorization
+// stops at the failing supernode): the limit is on the TARGET column, every column of A is walked.  k_add_beta then
+// adds beta to the diagonal (worker :510-520).
 //------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(256) void k_assemble_perm(
-    int64_t ncols, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+    int64_t ncols, int64_t climit, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
     const int64_t *__restrict__ Anz, const double *__restrict__ Ax, const int64_t *__restrict__ iperm,
     const int32_t *__restrict__ supermap, const int64_t *__restrict__ Super,
     const int64_t *__restrict__ Lpi, const int64_t *__restrict__ Lpx,
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void k_assemble_perm(
         const int64_t ki = iperm[i];
         const bool swap = ki < kj;
         const int64_t kc = swap ? ki : kj, kr = swap ? kj : ki;
+        if (kc >= climit) continue;
         const int s = supermap[kc];
         if (smask && !smask[s]) continue;
         const int64_t k1 = Super[s], psi = Lpi[s];

@@ -272,9 +272,9 @@ int emu_device_assemble(int kind, int E, int64_t n, int64_t nsuper, const int64_
     else if (kind == 0)
         hipcpu::launch_serial(grid, 256, [&] { k_assemble_c(n, Ap, Ai, Anz, Ax, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, beta, nomask); });
     else if (kind == 1 && E == 1)
-        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<1>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<1>(n, n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 1)
-        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<2>(n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
+        hipcpu::launch_serial(grid, 256, [&] { k_assemble_perm<2>(n, n, Ap, Ai, Anz, Ax, iperm, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 2 && E == 1)
         hipcpu::launch_serial(grid, 256, [&] { k_assemble_aat<1>(n, Ap, Ai, Anz, Ax, Fp, Fi, Fnz, Fx, supermap.data(), Super, Lpi, Lpx, ls32.data(), Lx, nomask); });
     else if (kind == 2)

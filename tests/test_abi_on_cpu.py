@@ -111,6 +111,12 @@ def test_device_side_permutation_rcond_and_simplicial(engine):
     L.close()
 
 
+@pytest.mark.parametrize("name", ["lap3d_8_npd200", "elast27_4_npd100", "lap2d_16_npd0", "tcov_c30lo_singular"])
+def test_device_side_permutation_not_posdef_through_the_abi(engine, name):
+    import test_gpu_parity as tp
+    tp.test_device_side_permutation_of_a_matrix_that_is_not_posdef(engine, name)
+
+
 # ---- this session's additions, which no GPU has run yet
 
 def test_unsym_through_the_abi(engine):

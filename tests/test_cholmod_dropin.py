@@ -127,6 +127,49 @@ def test_same_factor_as_unchanged_reference(which, name):
     r.close()
 
 
+@pytest.mark.parametrize("which", BOTH)
+def test_factorize_hands_over_the_unpermuted_matrix(which):
+    """cholmod_l_factorize on a lower-stored A with a fill-reducing ordering: the two cholmod_ptranspose calls that build
+    S = tril (P A P') (cholmod_factorize.c:228-238) are skipped, the device places A through L->Perm -- counted by
+    cholmod_mi355_calls_taken [3]; an upper-stored or zomplex A, the natural ordering and a conversion that needs S
+    afterwards (final_resymbol) keep the host copy.  The factor is the fixture's either way."""
+    def run(name, expect_deferred, **options):
+        g = load_golden(name)
+        n = g["n"]
+        r = _cholmod(which)
+        if options:
+            r.set_option(**options)
+        r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+        r.analyze(perm=g["Perm"], supernodal=2)
+        for _ in range(2):                                  # the second call refactorizes the same L
+            t0 = r.calls_taken()
+            assert r.factorize_full(beta=g["beta"]) == g["status"]
+            t1 = r.calls_taken()
+            assert t1[0] - t0[0] == 1
+            assert t1[3] - t0[3] == (1 if expect_deferred else 0), (name, options, t0, t1)
+            if not options:
+                assert r.info()["minor"] == g["minor"]
+                Lx = r.Lx()
+                assert np.array_equal(Lx == 0, g["Lx"] == 0) and relerr(Lx, g["Lx"]) < 1e-10
+            if g["status"] == 0:
+                A = _dense_A(g) + g["beta"] * np.eye(n)
+                X = r.solve(g["B"])
+                assert relerr(X, np.linalg.solve(A, g["B"])) < 1e-9
+            if options:
+                break                                       # L was converted: the next factorize is not supernodal
+        r.close()
+        return g
+    stypes = set()
+    for name in ("lap3d_8_metis", "helm3d_6_metis", "elast27_4_metis", "lap2d_16_metis", "lap3d_8_npd200"):
+        stypes.add(int(run(name, True)["stype"]))
+    assert stypes == {-1}
+    assert run("demo_bcsstk01", False)["stype"] > 0         # upper-stored: one ptranspose on the host, as before
+    assert run("tcov_z30lo", False)["xtype"] == 2           # zomplex A: the host copy
+    # final form simplicial with resymbol: cholmod_resymbol_noperm reads S after the numeric phase
+    run("lap3d_8_metis", False, final_asis=0, final_super=0, final_ll=1, final_resymbol=1)
+    run("lap3d_8_metis", True, final_asis=0, final_super=0, final_ll=1, final_resymbol=0)
+
+
 @pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "demo_c", "lap3d_8_metis", "helm3d_6_metis", "tcov_z30lo"]))
 def test_solve2_branch_on_the_device(which, name):
     """cholmod_l_solve2's supernodal branch (cholmod_solve.c:656-717) taken over as a whole: B down once, P, both sweeps

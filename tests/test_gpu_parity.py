@@ -639,6 +639,32 @@ def test_device_side_permutation_matches_host_permutation(engine, kind, size, be
         L3.set_matrix_perm(p["Ap"], p["Ai"], p["Ax"], bad)
 
 
+@pytest.mark.parametrize("name", ["lap3d_8_npd200", "elast27_4_npd100", "lap2d_16_npd0", "tcov_c30lo_singular"])
+def test_device_side_permutation_of_a_matrix_that_is_not_posdef(engine, name):
+    """mi355_factor_set_matrix_perm + a bad pivot: the replay of the failing supernode assembles the columns of S below
+    the limit from ALL columns of A (the limit is on the permuted target column) -- status, L->minor, zero pattern and
+    values as the reference left them (fixture), same as with the host-permuted S"""
+    import scipy.sparse as sp
+    from conftest import load_golden, sym_of
+    g = load_golden(name)
+    n = g["n"]
+    A = sp.csc_matrix((g["Ax"], g["Ai"], g["Ap"]), shape=(n, n))
+    if g["stype"] > 0:
+        A = A.conj().T.tocsc()
+    A = sp.tril(A, format="csc")
+    A.sort_indices()
+    cplx = g["xtype"] == 2
+    L = engine.SupernodalFactor(sym_of(g), xtype=2 if cplx else 1)
+    L.set_matrix_perm(A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data), g["Perm"])
+    for _ in range(2):
+        assert L.numeric(beta=g["beta"]) == g["status"] == 1
+        assert L.minor == g["minor"]
+        Lx = L.Lx()
+        assert np.array_equal(Lx == 0, g["Lx"] == 0)
+        assert relerr(Lx, g["Lx"]) < TOL_L
+    L.close()
+
+
 @pytest.mark.parametrize("kind,size", [("lap3d", 11), ("helm", 8), ("lap2d", 40)])
 def test_supernodal_to_simplicial_on_the_device(engine, kind, size, have_ref):
     """mi355_factor_to_simplicial against cholmod_l_change_factor of the reference applied to
