@@ -448,3 +448,52 @@ def test_solver_settings_of_the_reference(which, setting):
         assert relerr(X, Xu) < 1e-9
         assert _demo_resid(_dense_A(g), X, g["B"]) < 1e-7
         r.close(); u.close()
+
+
+@pytest.mark.parametrize("which", BOTH)
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_public_api_against_the_unchanged_build(which, seed):
+    """random SPD / Hermitian positive definite structures (sparse graphs, chains, arrows, dense blocks), lower-stored,
+    CHOLMOD's own ordering strategy, through analyze -> factorize -> solve2 of both builds: the same Perm and supernodal
+    structure (the hooks change nothing symbolic), L->x within 1e-10, the same solutions for A, L and Lt systems;
+    every third seed gets a negative pivot (status, minor and zero pattern as the unchanged build)"""
+    import scipy.sparse as sp
+    import test_fuzz_schedule as tf
+    rng = np.random.default_rng(500 + seed)
+    kind = ["sparse", "banded", "arrow", "blocks"][seed % 4]
+    n = int(rng.integers(60, 400))
+    Ap, Ai, Ax = tf.random_spd(kind, n, 40 + seed)
+    cplx = seed % 2 == 1
+    if cplx:                                    # Hermitian: imaginary parts off the diagonal only, magnitudes unchanged
+        ph = np.exp(1j * rng.uniform(0, 2 * np.pi, len(Ax)))
+        col = np.repeat(np.arange(n), np.diff(Ap))
+        ph[Ai == col] = 1.0
+        Ax = Ax * ph
+    spoil = seed % 3 == 2
+    if spoil:
+        k = int(rng.integers(0, n))
+        assert Ai[Ap[k]] == k
+        Ax = Ax.copy(); Ax[Ap[k]] = -abs(Ax[Ap[k]])
+    g = dict(n=n, Ap=Ap, Ai=Ai, Ax=Ax, stype=-1)
+    r, u = _both_builds(which, g)
+    for x in (r, u):
+        inf = x.analyze(ordering=-1, supernodal=2)
+        assert inf["is_super"] == 1
+    sr, su = r.symbolic(), u.symbolic()
+    for k in ("Perm", "Super", "Lpi", "Lpx", "Ls"):
+        assert np.array_equal(sr[k], su[k]), k
+    t0 = r.calls_taken()
+    st_r, st_u = r.factorize_full(), u.factorize_full()
+    t1 = r.calls_taken()
+    assert st_r == st_u == (NOT_POSDEF if spoil else 0)
+    assert t1[0] - t0[0] == 1 and r.counters()["cpu_blas_calls"] == 0
+    assert r.info()["minor"] == u.info()["minor"]
+    Lr, Lu = r.Lx(), u.Lx()
+    assert np.array_equal(Lr == 0, Lu == 0) and relerr(Lr, Lu) < 1e-10
+    if not spoil:
+        B = rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if seed % 4 == 3 else 0)
+        for sys in ("A", "L", "Lt"):
+            assert relerr(r.solve2(sys, B), u.solve2(sys, B)) < 1e-9, sys
+        A = _dense_A(g)
+        assert _demo_resid(A, r.solve2("A", B), B) < 1e-12
+    r.close(); u.close()
