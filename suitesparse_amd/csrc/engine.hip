@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -148,9 +149,23 @@ __global__ void k_first_info(int64_t nsuper, const int *__restrict__ info, int *
     if (s < nsuper && info[s] != 0) atomicMin(out, (int)s);
 }
 
+// MI355_CREATE_LOG=1: host seconds of the phases of mi355_factor_create / upload_schedule on stderr
+struct PhaseClock {
+    bool on = getenv("MI355_CREATE_LOG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mi355 create] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
 {
     Schedule &S = D.sched;
+    PhaseClock pc;
     {
         // no task may point outside the arrays the kernels index with it (a GPU memory fault takes the machine down)
         // (Dinv is sized by the full schedule: all blocks)
@@ -158,12 +173,14 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
         if (bad.compare(0, 10, "too large:") == 0) return fail(MI355_TOO_LARGE, bad);
         if (!bad.empty()) return fail(MI355_GPU_PROBLEM, "internal: schedule rejected before upload: " + bad);
     }
+    pc.lap("check_schedule_bounds");
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
     if (!S.potrf_order.empty()) HIP_TRY(D.potrf_order.upload(S.potrf_order.data(), S.potrf_order.size(), F->stream));
     HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_tab.data(), S.gemm_tile_tab.size(), F->stream));
     HIP_TRY(D.solve_tmap.upload(S.solve_tile_task.data(), S.solve_tile_task.size(), F->stream));
     HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
+    pc.lap("upload task lists");
     if (S.relmap_size > 0) {
         std::vector<RelmapPair> rp(S.pairs.size());
         for (size_t i = 0; i < rp.size(); i++) {
@@ -185,6 +202,7 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
         HIP_TRY(hipStreamSynchronize(F->stream));
         if (herr) return fail(MI355_INVALID, "symbolic factor invalid: a descendant row is missing from its ancestor");
     }
+    pc.lap("relmap (device)");
     return MI355_OK;
 }
 
@@ -452,6 +470,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
         HIP_TRY(hipEventCreate(&F->ev1));
     }
 
+    PhaseClock pc;
     F->Super.assign(Super, Super + (nsuper > 0 ? nsuper + 1 : 0));
     F->Lpi.assign(Lpi, Lpi + (nsuper > 0 ? nsuper + 1 : 0));
     F->Lpx.assign(Lpx, Lpx + (nsuper > 0 ? nsuper + 1 : 0));
@@ -464,9 +483,11 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     const std::string bad = validate_symbolic(F->sym);
     if (bad.compare(0, 10, "too large:") == 0) return fail(MI355_TOO_LARGE, bad);
     if (!bad.empty()) return fail(MI355_INVALID, "invalid supernodal symbolic factor: " + bad);
+    pc.lap("copy + validate_symbolic");
 
     F->sym.cplx = (F->E == 2);          // the big-tile kernel then covers 64 x 128 complex entries per tile
     build_schedule(F->sym, nsuper, 0, F->full.sched);
+    pc.lap("build_schedule");
 
     // device copies of the symbolic arrays (row indices narrowed to int32)
     std::vector<int32_t> ls32((size_t)nls);
@@ -479,6 +500,7 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     HIP_TRY(F->Lx.alloc((size_t)xsize * F->E));
     HIP_TRY(F->Dinv.alloc((size_t)F->full.sched.dinv_size * F->E));
     HIP_TRY(F->info.alloc((size_t)nsuper + 2));
+    pc.lap("device arrays");
     int rc = upload_schedule(F, F->full);
     if (rc != MI355_OK) return rc;
     guard.f = nullptr;
