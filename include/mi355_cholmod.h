@@ -112,6 +112,22 @@ int mi355_factor_numeric(mi355_factor *handle, double beta_re,
 /* Copy the numeric factor to the host array L->x (E*xsize doubles). */
 int mi355_factor_get_Lx(mi355_factor *handle, double *Lx);
 
+/* mi355_factor_numeric + mi355_factor_get_Lx in one, with the copy UNDER the factorization: L->x on the host is part
+ * of cholmod_super_numeric's contract (cholmod_solve, cholmod_change_factor, cholmod_rcond and the user read it), and at
+ * 150^3 it is 56 GB over PCIe -- more time than the factorization itself.  Lx is cut into chunks of whole supernodes
+ * (about 256 MB); a chunk leaves for the host as soon as the levels of its supernodes are complete, copied by a thread
+ * of its own on a stream of its own while the main thread goes on enqueueing kernels (Lx may be pageable memory).  The
+ * bottom of the elimination tree -- most supernodes, about half the bytes -- is on the host before the top is
+ * factorized.  Same results as the two calls; a matrix that is not positive definite gets one plain copy after the
+ * reference's repeat-supernode protocol has run.  mi355_factor_get_stats reports how much left early. */
+int mi355_factor_numeric_host(mi355_factor *handle, double beta_re, int quick_return_if_not_posdef,
+                              double *Lx, int64_t *minor, int *status);
+
+/* The chunks: `count` rows of 4 int64 (lo, hi, ready, flops) -- entries Lx[lo, hi) may be copied once the first `ready`
+ * launches of the factorization have run, which execute `flops` of its flops (a multiply and an add counted once each,
+ * like Common->fl).  Diagnostic; plan may be NULL to ask for count only. */
+int mi355_factor_host_copy_plan(mi355_factor *handle, int64_t cap, int64_t *plan, int64_t *count);
+
 /* cholmod_rcond on the device-resident factor (CHOLMOD/Cholesky/cholmod_rcond.c:51-110, supernodal LL' branch of
  * t_cholmod_rcond_worker.c:76-99,132-137): (min L(j,j) / max L(j,j))^2 over the real parts of the diagonal, 0 if one
  * of them is NaN or the last factorization was not positive definite, 1 for n = 0.  Reads n doubles of HBM; the
@@ -337,7 +353,7 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *             9 number of (d,s) update pairs              10 number of levels
  *            11 relative-map entries                      12 block-inverse entries
  *            13 ms of the last solve call                 14 GEMM tiles launched
- *            15 reserved
+ *            15 entries of Lx that the last mi355_factor_numeric_host handed to the host copy before its last launch
  *            16 ms in k_gemm128 launches (part of 1)      17 number of k_gemm128 launches
  *            18 useful flops of the tasks in k_gemm128    19 useful flops of the tasks in k_gemm64
  *            20 k_gemm128 tiles per factorization         21 k_gemm64 tiles
@@ -368,7 +384,8 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * the part that targets the NEXT block runs before that block's panel chain, the rest after the chain's broadcast has been
  * issued, so chain and broadcast overlap it; 0: the whole update first); key 17: a block of the distributed top is
  * broadcast in finished pieces of the first nested width (key 2: 256 columns) while its panel chain is still running
- * (default 1; 0: in one piece when it is complete); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * (default 1; 0: in one piece when it is complete); key 18: entries of Lx per chunk of mi355_factor_numeric_host
+ * (default 32 Mi = 256 MB real; read when a handle copies for the first time); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -285,9 +285,10 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
                     (const double *) A->x) ;
         }
         // only beta [0] is used (t_cholmod_super_numeric_worker.c:510-520)
-        if (rc == MI355_OK) rc = mi355_factor_numeric (h, beta [0], Common->quick_return_if_not_posdef, &minor, &status) ;
-        // L->x on the host is part of the contract: cholmod_solve, change_factor, rcond, factor_to_sparse read it
-        if (rc == MI355_OK) rc = mi355_factor_get_Lx (h, (double *) L->x) ;
+        // L->x on the host is part of the contract (cholmod_solve, change_factor, rcond, factor_to_sparse and the user
+        // read it): it is filled chunk by chunk WHILE the factorization runs, the bottom of the tree first
+        if (rc == MI355_OK) rc = mi355_factor_numeric_host (h, beta [0], Common->quick_return_if_not_posdef,
+                (double *) L->x, &minor, &status) ;
     }
     if (rc != MI355_OK)
     {

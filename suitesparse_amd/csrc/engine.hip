@@ -15,6 +15,11 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../include/mi355_cholmod.h"
 #include "schedule.hpp"
@@ -139,6 +144,11 @@ struct mi355_factor_s {
     double st_ngemm = 0, st_npotrf = 0, st_tiles = 0, st_nbig = 0, st_big = 0;
     EventTimer *timer = nullptr;   // events of the last profiled numeric call, collected lazily
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket of one numeric / solve call (created once: no leak on error paths)
+    // mi355_factor_numeric_host: chunks of Lx go to the host as soon as they are final
+    std::vector<HostCopyChunk> copy_plan;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_ev;            // one per chunk, created on first use
+    double st_copy_early = 0;                   // entries copied before the last step had been enqueued
 };
 
 namespace {
@@ -260,9 +270,79 @@ struct EventTimer {
     }
 };
 
+// Copies chunks of the device factor to the host on a thread of its own while the main thread goes on enqueueing the
+// factorization: the thread waits for a chunk's event (recorded on the compute stream after the chunk's last writer),
+// then copies on the copy stream.  A blocking copy into pageable memory (L->x is cholmod_malloc'ed) therefore never
+// holds up the enqueueing of kernels.
+struct HostCopier {
+    struct Item { hipEvent_t ev; int64_t lo, hi; };
+    mi355_factor_s *F;
+    double *dst;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Item> q;
+    bool closed = false;
+    hipError_t err = hipSuccess;
+    size_t next = 0;            // next chunk of F->copy_plan to hand over (main thread)
+    HostCopier(mi355_factor_s *F_, double *dst_) : F(F_), dst(dst_) { th = std::thread([this] { run(); }); }
+    ~HostCopier() { (void)finish(); }
+    void run()
+    {
+        hipError_t e = hipSetDevice(F->device);
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return closed || !q.empty(); });
+                if (q.empty()) break;
+                it = q.front();
+                q.pop_front();
+            }
+            if (e != hipSuccess) continue;      // keep draining so that finish() returns
+            e = hipEventSynchronize(it.ev);
+            const size_t E = (size_t)F->E;
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(dst + (size_t)it.lo * E, F->Lx.p + (size_t)it.lo * E,
+                                   (size_t)(it.hi - it.lo) * E * sizeof(double), hipMemcpyDeviceToHost, F->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(F->copy_stream);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        err = e;
+    }
+    // main thread: chunk k is final on stream `st` from here on
+    int hand_over(size_t k, hipStream_t st)
+    {
+        while (F->copy_ev.size() <= k) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            F->copy_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(F->copy_ev[k], st));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back({F->copy_ev[k], F->copy_plan[k].lo, F->copy_plan[k].hi});
+        }
+        cv.notify_one();
+        return MI355_OK;
+    }
+    // wait for every copy handed over so far; the thread ends
+    int finish()
+    {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); closed = true; }
+            cv.notify_one();
+            th.join();
+        }
+        if (err != hipSuccess) return fail(MI355_GPU_PROBLEM, std::string("copy of the factor to the host failed: ") + hipGetErrorString(err));
+        return MI355_OK;
+    }
+};
+
 // run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
 int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm,
-                 const int8_t *smask = nullptr, bool init = true, int64_t step0 = 0, int64_t step1 = -1)
+                 const int8_t *smask = nullptr, bool init = true, int64_t step0 = 0, int64_t step1 = -1,
+                 HostCopier *hc = nullptr)
 {
     const Symbolic &S = F->sym;
     tm.begin(2);
@@ -305,7 +385,22 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
     struct LogCloser { FILE *&f; hipEvent_t &a, &b; ~LogCloser() { if (f) { fclose(f); (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } } closer{steplog, le0, le1};
     if (step1 < 0) step1 = (int64_t)D.sched.steps.size();
     bool side_pending = false;
+    // chunks of Lx that are final once the first si steps have run go to the host now
+    auto hand_over_ready = [&](int64_t si) -> int {
+        while (hc && hc->next < F->copy_plan.size() && F->copy_plan[hc->next].ready_step <= si) {
+            if (side_pending) {         // a far update on the side stream may still be writing
+                HIP_TRY(hipStreamWaitEvent(F->stream, F->side_ev[1], 0));
+                side_pending = false;
+            }
+            int rc = hc->hand_over(hc->next, F->stream);
+            if (rc) return rc;
+            if (si < step1) F->st_copy_early += (double)(F->copy_plan[hc->next].hi - F->copy_plan[hc->next].lo);
+            hc->next++;
+        }
+        return MI355_OK;
+    };
     for (int64_t si = step0; si < step1; si++) {
+        { int rc = hand_over_ready(si); if (rc) return rc; }
         const Step &st = D.sched.steps[(size_t)si];
         if (st.count <= 0) continue;
         // look-ahead fork/join (schedule.hpp): `q` is the stream this step launches on
@@ -403,8 +498,8 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             }
         }
     }
-    if (side_pending) HIP_TRY(hipStreamWaitEvent(F->stream, F->side_ev[1], 0));
-    return MI355_OK;
+    if (side_pending) { HIP_TRY(hipStreamWaitEvent(F->stream, F->side_ev[1], 0)); side_pending = false; }
+    return hand_over_ready(step1);
 }
 
 int check_handle(mi355_factor_s *F)
@@ -515,6 +610,8 @@ int mi355_factor_free(mi355_factor *F)
     if (F->side) { (void)hipStreamSynchronize(F->side); (void)hipStreamDestroy(F->side); }
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
     for (hipEvent_t ev : F->side_ev) (void)hipEventDestroy(ev);
+    if (F->copy_stream) { (void)hipStreamSynchronize(F->copy_stream); (void)hipStreamDestroy(F->copy_stream); }
+    for (hipEvent_t ev : F->copy_ev) (void)hipEventDestroy(ev);
     if (F->ev0) (void)hipEventDestroy(F->ev0);
     if (F->ev1) (void)hipEventDestroy(F->ev1);
     if (F->timer) { F->timer->drop(); F->timer->destroy_pool(); delete F->timer; }
@@ -632,14 +729,33 @@ int mi355_factor_set_matrix_zomplex(mi355_factor *F, const int64_t *Ap, const in
     return set_matrix_impl(F, Ap, Ai, Anz, Ax, Az);
 }
 
-int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_not_posdef,
-                         int64_t *minor, int *status)
+}  // extern "C"
+
+namespace {
+
+// the numeric factorization; host_Lx != NULL: L->x on the host is filled as well, chunk by chunk while the
+// factorization runs (mi355_factor_numeric_host)
+int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef, int64_t *minor, int *status,
+                 double *host_Lx)
 {
     g_err.clear();
     int rc = check_handle(F);
     if (rc) return rc;
     if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
     const Symbolic &S = F->sym;
+    F->st_copy_early = 0;
+    std::unique_ptr<HostCopier> hc;
+    if (host_Lx && S.xsize > 0 && S.nsuper > 0) {
+        if (!F->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&F->copy_stream, hipStreamNonBlocking));
+        if (F->copy_plan.empty()) {
+            // chunks of 32 M entries (256 MB real): large enough for PCIe to run at its rate, small enough that the
+            // bottom of the tree leaves while the top is still being factorized
+            build_host_copy_plan(S, F->full.sched, std::max(1, tuning().host_chunk), F->copy_plan);
+            const std::string bad = check_host_copy_plan(S, F->full.sched, F->copy_plan);
+            if (!bad.empty()) { F->copy_plan.clear(); return fail(MI355_GPU_PROBLEM, "internal: " + bad); }
+        }
+        hc.reset(new HostCopier(F, host_Lx));
+    }
     F->numeric_ok = false;
     F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
@@ -657,7 +773,7 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     const hipEvent_t e0 = F->ev0, e1 = F->ev1;
     HIP_TRY(hipEventRecord(e0, F->stream));
 
-    rc = run_schedule(F, F->full, S.n, beta_re, tm);
+    rc = run_schedule(F, F->full, S.n, beta_re, tm, nullptr, true, 0, -1, hc.get());
     if (rc) return rc;
     int *first = F->info.p + S.nsuper;
     const int big = 0x7f7f7f7f;
@@ -691,6 +807,16 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
             HIP_TRY(hipMemsetAsync(F->Lx.p + tail * F->E, 0, (size_t)(S.xsize - tail) * F->E * sizeof(double), F->stream));
         HIP_TRY(hipStreamSynchronize(F->stream));
     }
+    if (hc) {
+        rc = hc->finish();
+        if (rc) return rc;
+        if (sf != big) {
+            // the rare failing case: what left early is not what the replay produced -- one plain copy of everything
+            F->st_copy_early = 0;
+            HIP_TRY(hipMemcpyAsync(host_Lx, F->Lx.p, (size_t)S.xsize * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+            HIP_TRY(hipStreamSynchronize(F->stream));
+        }
+    }
     HIP_TRY(hipEventRecord(e1, F->stream));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -702,6 +828,60 @@ int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_no
     F->not_posdef = (st_out == MI355_STATUS_NOT_POSDEF);
     if (minor) *minor = minor_out;
     if (status) *status = st_out;
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_factor_numeric(mi355_factor *F, double beta_re, int quick_return_if_not_posdef,
+                         int64_t *minor, int *status)
+{
+    return numeric_impl(F, beta_re, quick_return_if_not_posdef, minor, status, nullptr);
+}
+
+int mi355_factor_numeric_host(mi355_factor *F, double beta_re, int quick_return_if_not_posdef,
+                              double *Lx, int64_t *minor, int *status)
+{
+    if (!Lx && F && F->sym.xsize > 0) return fail(MI355_INVALID, "null Lx");
+    return numeric_impl(F, beta_re, quick_return_if_not_posdef, minor, status, Lx);
+}
+
+int mi355_factor_host_copy_plan(mi355_factor *F, int64_t cap, int64_t *plan, int64_t *count)
+{
+    g_err.clear();
+    if (!F || !count) return fail(MI355_INVALID, "null argument");
+    if (F->copy_plan.empty() && F->sym.xsize > 0 && F->sym.nsuper > 0) {
+        build_host_copy_plan(F->sym, F->full.sched, std::max(1, tuning().host_chunk), F->copy_plan);
+        const std::string bad = check_host_copy_plan(F->sym, F->full.sched, F->copy_plan);
+        if (!bad.empty()) { F->copy_plan.clear(); return fail(MI355_GPU_PROBLEM, "internal: " + bad); }
+    }
+    *count = (int64_t)F->copy_plan.size();
+    if (!plan) return MI355_OK;
+    if (cap < *count) return fail(MI355_INVALID, "plan buffer too small");
+    // flops of the launches that precede each step (what the device has done when a chunk may leave)
+    const Schedule &sc = F->full.sched;
+    std::vector<double> before(sc.steps.size() + 1, 0.0);
+    for (size_t si = 0; si < sc.steps.size(); si++) {
+        const Step &st = sc.steps[si];
+        double fl = 0;
+        for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+            if (st.kind == STEP_POTRF) {
+                const double nb = sc.potrf[(size_t)ti].nb;
+                fl += nb * nb * nb / 3.0;
+            } else {
+                const GemmTask &t = sc.gemm[(size_t)ti];
+                const double Mm = t.M, Nn = t.N, Kk = t.K;
+                fl += (t.mode == GEMM_OVERWRITE) ? Mm * Nn * Kk : (Nn * Nn + 2.0 * (Mm - Nn) * Nn) * Kk;
+            }
+        }
+        before[si + 1] = before[si] + fl;
+    }
+    for (size_t k = 0; k < F->copy_plan.size(); k++) {
+        plan[4 * k] = F->copy_plan[k].lo; plan[4 * k + 1] = F->copy_plan[k].hi; plan[4 * k + 2] = F->copy_plan[k].ready_step;
+        plan[4 * k + 3] = (int64_t)before[(size_t)F->copy_plan[k].ready_step];
+    }
     return MI355_OK;
 }
 
@@ -859,9 +1039,7 @@ int mi355_super_numeric(mi355_factor *F, const int64_t *Ap, const int64_t *Ai, c
 {
     int rc = mi355_factor_set_matrix(F, Ap, Ai, Anz, Ax);
     if (rc) return rc;
-    rc = mi355_factor_numeric(F, beta_re, quick_return_if_not_posdef, minor, status);
-    if (rc) return rc;
-    return mi355_factor_get_Lx(F, Lx);
+    return mi355_factor_numeric_host(F, beta_re, quick_return_if_not_posdef, Lx, minor, status);
 }
 
 int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const int8_t *top_mask,
@@ -1565,6 +1743,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 15) tuning().solve_fwd_div_mma = std::max(1, value);
     else if (key == 16) tuning().dist_lookahead = value ? 1 : 0;
     else if (key == 17) tuning().dist_pieces = value ? 1 : 0;
+    else if (key == 18) tuning().host_chunk = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -1681,7 +1860,7 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
     out[4] = F->st_npotrf; out[5] = F->st_asm; out[6] = S.flops_update; out[7] = S.flops_panel;
     out[8] = S.bytes_assembly; out[9] = (double)S.pairs.size(); out[10] = (double)S.nlevels;
     out[11] = (double)S.relmap_size; out[12] = (double)S.dinv_size; out[13] = F->st_solve;
-    out[14] = F->st_tiles; out[15] = 0;
+    out[14] = F->st_tiles; out[15] = F->st_copy_early;
     out[16] = F->st_big; out[17] = F->st_nbig; out[18] = S.flops_big; out[19] = S.flops_small;
     out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[23] = 0;
     // useful k_gemm128 flops THIS handle executes per factorization: all of them, or its share of a partition

@@ -641,6 +641,80 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
     }
 }
 
+void build_host_copy_plan(const Symbolic &S, const Schedule &sc, int64_t min_entries, std::vector<HostCopyChunk> &out)
+{
+    out.clear();
+    if (S.nsuper <= 0 || S.xsize <= 0) return;
+    // steps are in level order: after[l] = number of steps whose level is <= l.  Supernode s (level l) is written by its
+    // own panel steps and by the update steps of LOWER levels only, so it is final once after[l] steps have run
+    std::vector<int64_t> after((size_t)sc.nlevels + 1, 0);
+    for (const Step &st : sc.steps) after[(size_t)st.level]++;
+    for (int l = 1; l <= sc.nlevels; l++) after[(size_t)l] += after[(size_t)l - 1];
+    const int64_t small = std::max<int64_t>(1, min_entries / 8);
+    HostCopyChunk c{S.Lpx[0], S.Lpx[0], 0};
+    if (c.lo > 0) out.push_back({0, c.lo, 0});      // (Lpx[0] is 0 in every factor CHOLMOD builds)
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        const int64_t ready = after[(size_t)sc.level[(size_t)s]];
+        const int64_t have = c.hi - c.lo;
+        if (have >= min_entries || (have >= small && ready > c.ready_step)) {
+            out.push_back(c);
+            c = HostCopyChunk{c.hi, c.hi, 0};
+        }
+        c.hi = S.Lpx[s + 1];
+        c.ready_step = std::max(c.ready_step, ready);
+    }
+    c.hi = S.xsize;
+    if (c.hi > c.lo) out.push_back(c);
+}
+
+std::string check_host_copy_plan(const Symbolic &S, const Schedule &sc, const std::vector<HostCopyChunk> &plan)
+{
+    char buf[200];
+    int64_t at = 0;
+    for (size_t k = 0; k < plan.size(); k++) {
+        if (plan[k].lo != at || plan[k].hi <= plan[k].lo) return "host copy plan: the chunks do not tile Lx";
+        if (plan[k].ready_step < 0 || plan[k].ready_step > (int64_t)sc.steps.size()) return "host copy plan: ready step out of range";
+        at = plan[k].hi;
+    }
+    if (at != (plan.empty() ? 0 : S.xsize)) return "host copy plan: the chunks do not cover Lx";
+    if (plan.empty()) return "";
+    // latest step that writes each chunk
+    std::vector<int64_t> last_write(plan.size(), -1);
+    auto mark = [&](int64_t lo, int64_t hi /* inclusive */, int64_t step) {
+        size_t k = (size_t)(std::upper_bound(plan.begin(), plan.end(), lo,
+                            [](int64_t v, const HostCopyChunk &c) { return v < c.lo; }) - plan.begin()) - 1;
+        for (; k < plan.size() && plan[k].lo <= hi; k++) last_write[k] = std::max(last_write[k], step);
+    };
+    auto super_of = [&](int64_t off) {          // supernode whose values hold entry off
+        return (int64_t)(std::upper_bound(S.Lpx, S.Lpx + S.nsuper + 1, off) - S.Lpx) - 1;
+    };
+    for (size_t si = 0; si < sc.steps.size(); si++) {
+        const Step &st = sc.steps[si];
+        for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+            if (st.kind == STEP_POTRF) {
+                const PotrfTask &t = sc.potrf[(size_t)ti];
+                mark(S.Lpx[t.s], S.Lpx[t.s + 1] - 1, (int64_t)si);         // the block (and, fused, the rows below it)
+            } else {
+                const GemmTask &t = sc.gemm[(size_t)ti];
+                if (t.mode == GEMM_SCATTER_SUB) {
+                    const int64_t a = super_of(t.c_off);
+                    if (a < 0 || a >= S.nsuper) return "host copy plan: scatter target outside Lx";
+                    mark(S.Lpx[a], S.Lpx[a + 1] - 1, (int64_t)si);
+                } else {
+                    mark(t.c_off, t.c_off + (t.M - 1) + (int64_t)(t.N - 1) * t.ldc, (int64_t)si);
+                }
+            }
+        }
+    }
+    for (size_t k = 0; k < plan.size(); k++)
+        if (last_write[k] >= plan[k].ready_step) {
+            snprintf(buf, sizeof buf, "host copy plan: chunk %lld is ready after %lld steps but step %lld writes it",
+                     (long long)k, (long long)plan[k].ready_step, (long long)last_write[k]);
+            return std::string(buf);
+        }
+    return "";
+}
+
 std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss, int64_t dinv_extent)
 {
     char buf[256];

@@ -216,7 +216,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; int dist_lookahead = 1; int dist_pieces = 1; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);
@@ -227,6 +227,14 @@ void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedul
 // outside its arrays is a GPU memory fault, and that takes the machine down, not just the process.
 std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const SolveSchedule *ss = nullptr,
                                   int64_t dinv_extent = -1 /* entries of the Dinv buffer; default: sc.dinv_size */);
+
+// Copy of the factor to the host WHILE it is being computed (mi355_factor_numeric_host): Lx is cut into chunks of whole
+// supernodes; a chunk may be copied once the first `ready_step` steps of the schedule have run -- nothing after them
+// writes into it (its supernodes' levels are complete).  min_entries: smallest chunk worth a copy of its own.
+struct HostCopyChunk { int64_t lo, hi, ready_step; };
+void build_host_copy_plan(const Symbolic &S, const Schedule &sc, int64_t min_entries, std::vector<HostCopyChunk> &out);
+// "" or why the plan is wrong: the chunks must tile [0, xsize) and no step at or after a chunk's ready_step may write it
+std::string check_host_copy_plan(const Symbolic &S, const Schedule &sc, const std::vector<HostCopyChunk> &plan);
 
 // true if the table of step st lists every valid tile of every task of the step exactly once
 bool check_tile_table(const Schedule &sc, const Step &st);

@@ -30,6 +30,7 @@ _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 EXPORTS = [
     "mi355_probe", "mi355_last_error", "mi355_factor_create", "mi355_factor_free",
     "mi355_factor_set_matrix", "mi355_factor_numeric", "mi355_factor_get_Lx",
+    "mi355_factor_numeric_host", "mi355_factor_host_copy_plan",
     "mi355_super_numeric", "mi355_super_lsolve", "mi355_super_ltsolve",
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
@@ -250,7 +251,7 @@ class Comm:
 
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
              "flops_update", "flops_panel", "bytes_assembly", "npairs", "nlevels", "relmap_entries",
-             "dinv_entries", "solve_ms", "gemm_tiles", "reserved", "gemm128_ms", "gemm128_launches",
+             "dinv_entries", "solve_ms", "gemm_tiles", "copy_early_entries", "gemm128_ms", "gemm128_launches",
              "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "flops_gemm128_here", "reserved3"]
 
 
@@ -394,6 +395,32 @@ class SupernodalFactor:
                                           C.byref(minor), C.byref(status)))
         self.minor, self.status = int(minor.value), int(status.value)
         return self.status
+
+    def numeric_host(self, beta=0.0, quick_return_if_not_posdef=False):
+        """mi355_factor_numeric_host: factorize and fill a host L->x while the factorization runs; returns
+        (status, Lx)"""
+        minor = C.c_int64(0)
+        status = C.c_int(0)
+        out = np.full(max(self.xsize, 1) * self.E, np.nan)
+        f = lib().mi355_factor_numeric_host
+        f.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        _check(f(self._h, float(beta), int(bool(quick_return_if_not_posdef)), out.ctypes.data_as(C.c_void_p),
+                 C.byref(minor), C.byref(status)))
+        self.minor, self.status = int(minor.value), int(status.value)
+        out = out[:self.xsize * self.E]
+        return self.status, (out.view(np.complex128) if self.E == 2 else out)
+
+    def host_copy_plan(self):
+        """rows (lo, hi, ready_step, flops executed before ready_step) of the chunks of Lx that
+        mi355_factor_numeric_host copies early"""
+        f = lib().mi355_factor_host_copy_plan
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+        cnt = C.c_int64(0)
+        _check(f(self._h, 0, None, C.byref(cnt)))
+        plan = np.zeros((cnt.value, 4), dtype=np.int64)
+        if cnt.value:
+            _check(f(self._h, cnt.value, plan.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return plan
 
     def super_numeric(self, Sp, Si, Sx, beta=(0.0, 0.0), quick_return_if_not_posdef=False, Snz=None, Sz=None,
                       F=None):

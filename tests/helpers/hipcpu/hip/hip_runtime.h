@@ -331,6 +331,7 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::strcpy(
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (void *)1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreateWithPriority(s, 0, 0); }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

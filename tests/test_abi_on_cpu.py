@@ -412,3 +412,11 @@ def test_blas_timer_statistics(engine):
     assert (st3["gemm_launches"], st3["potrf_launches"]) == n1 and st3["total_ms"] > 0
     assert st3["gemm_ms"] == st2["gemm_ms"]             # nothing new was measured: the last profiled call's times stay
     L.close()
+
+
+@pytest.mark.parametrize("name,chunk", [("lap3d_8_metis", 2000), ("helm3d_6_metis", 500), ("elast27_4_metis", 4000),
+                                         ("lap2d_16_metis", 300), ("demo_bcsstk02", 1 << 25), ("lap3d_8_npd200", 2000),
+                                         ("lap2d_16_npd0", 300), ("tcov_c30lo_singular", 50)])
+def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
+    import test_gpu_parity as tp
+    tp.test_numeric_host_copies_under_the_factorization(engine, name, chunk)

@@ -8,6 +8,8 @@ for P in elast helm lap2d; do
     timeout -k 10 300 python -u bench.py --problem $P --steps 5 --warmup 2 > $O/bench_$P.json 2> $O/bench_$P.err || exit $?
     tail -c 1200 $O/bench_$P.json
 done
+timeout -k 10 240 python -u tools/time_host_inclusive.py 100 $O/host_inclusive_lap3d100.json > $O/host_inclusive.log 2>&1 || { tail -5 $O/host_inclusive.log; exit 1; }
+tail -1 $O/host_inclusive.log
 timeout -k 10 200 bash tools/solve_profile.sh 64 > $O/solve_nrhs64.txt 2>&1 || exit $?
 timeout -k 10 200 python -u -m pytest tests/wip_tiny_tasks.py -m gpu -x -q --timeout 120 --timeout-method thread > $O/wip_tiny.log 2>&1 || { tail -20 $O/wip_tiny.log; exit 1; }
 for K in 0 256 2048 16384; do
