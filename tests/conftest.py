@@ -11,6 +11,19 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Files whose GPU cases have not run on a GPU yet (written while GPU use was closed) are collected AFTER the files that
+# were green on the MI355X in round 1: the round-end run is `pytest -x`, and a first-run surprise in new code must not
+# hide the established parity tests.  A file named test_zz_* still comes last of all.
+RUN_LATE = ("test_cholmod_dropin.py", "test_multi_abi.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return 2 if name.startswith("test_zz") else 1 if name in RUN_LATE else 0
+    items.sort(key=rank)            # stable: the order inside each group stays pytest's
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
