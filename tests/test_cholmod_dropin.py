@@ -160,7 +160,8 @@ def test_factorize_hands_over_the_unpermuted_matrix(which):
         r.close()
         return g
     stypes = set()
-    for name in ("lap3d_8_metis", "helm3d_6_metis", "elast27_4_metis", "lap2d_16_metis", "lap3d_8_npd200"):
+    names = ("helm3d_6_metis", "elast27_4_metis", "lap2d_16_metis", "lap2d_16_npd0")
+    for name in names + (("lap3d_8_metis", "lap3d_8_npd200") if which == "gpu" else ()):    # (seconds each on the CPU build)
         stypes.add(int(run(name, True)["stype"]))
     assert stypes == {-1}
     assert run("demo_bcsstk01", False)["stype"] > 0         # upper-stored: one ptranspose on the host, as before

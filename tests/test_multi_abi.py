@@ -248,7 +248,7 @@ def bordered(nleaf, wleaf, border, seed):
 
 @pytest.mark.parametrize("world,defer,lookahead,pieces,spoil", [
     (2, True, 1, 1, False), (3, False, 1, 1, False), (2, True, 0, 1, False), (4, True, 1, 1, False),
-    (2, True, 1, 0, False), (3, True, 1, 1, True)])
+    (2, True, 1, 0, False), (2, True, 1, 1, True)])
 def test_a_wide_top_supernode_travels_in_pieces(engine, world, defer, lookahead, pieces, spoil):
     """a top supernode of 420 columns with blocks of 256 and a first nested width of 128: four ranges travel (columns
     0-127 and 128-255 of block 0, 256-383 and 384-419 of block 1), the first of each block while its chain is still
