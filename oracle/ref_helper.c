@@ -464,7 +464,10 @@ int cholmod_mi355_live_handles (void) ;
 void cholmod_mi355_calls_taken (int64_t out [4]) ;
 int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
 void ref_calls_taken (int64_t *out) { cholmod_mi355_calls_taken (out) ; }
+void cholmod_mi355_forget (cholmod_factor *L) ;
+void ref_forget (void *hv) { cholmod_mi355_forget (((ref_ctx *) hv)->L) ; }
 #else
+void ref_forget (void *hv) { (void) hv ; }
 int ref_live_handles (void) { return -1 ; }
 void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = out [3] = -1 ; }
 #endif

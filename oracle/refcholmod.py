@@ -184,6 +184,11 @@ class RefCholmod:
             return out.view(np.complex128).reshape(nrhs, n).T.copy()
         return (out[:n * nrhs] + 1j * out[n * nrhs:]).reshape(nrhs, n).T.copy()
 
+    def forget(self):
+        """cholmod_mi355_forget (L): drop the device image of the factor (drop-in build only)"""
+        self.L.ref_forget.argtypes = [C.c_void_p]
+        self.L.ref_forget(self.h)
+
     def drop_factor(self):
         self.L.ref_drop_factor(self.h)
 

@@ -171,6 +171,28 @@ def test_factorize_hands_over_the_unpermuted_matrix(which):
     run("lap3d_8_metis", True, final_asis=0, final_super=0, final_ll=1, final_resymbol=0)
 
 
+@pytest.mark.parametrize("which", BOTH)
+def test_hand_edited_factor_after_forget(which):
+    """INTEGRATION.md, "what the device image assumes": a caller who rewrites L->x by hand calls cholmod_mi355_forget (L);
+    the solves then run on the CPU workers from L->x (here L scaled by 2, so the solution shrinks by 4)"""
+    g = load_golden("demo_bcsstk02")
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    base = r.live_handles()
+    X = r.solve(g["B"])
+    r.set_Lx(2.0 * r.Lx())
+    r.forget()
+    assert r.live_handles() == base - 1
+    t0 = r.calls_taken()
+    X2 = r.solve(g["B"])
+    assert r.calls_taken() == t0                    # nothing was taken over: the CPU workers answered
+    assert relerr(4.0 * X2, X) < 1e-12
+    r.close()
+
+
 @pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "demo_c", "lap3d_8_metis", "helm3d_6_metis", "tcov_z30lo"]))
 def test_solve2_branch_on_the_device(which, name):
     """cholmod_l_solve2's supernodal branch (cholmod_solve.c:656-717) taken over as a whole: B down once, P, both sweeps
