@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -754,7 +755,11 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
             const std::string bad = check_host_copy_plan(S, F->full.sched, F->copy_plan);
             if (!bad.empty()) { F->copy_plan.clear(); return fail(MI355_GPU_PROBLEM, "internal: " + bad); }
         }
-        hc.reset(new HostCopier(F, host_Lx));
+        try {
+            hc.reset(new HostCopier(F, host_Lx));
+        } catch (const std::exception &e) {       // no thread to be had: nothing was started
+            return fail(MI355_OUT_OF_MEMORY, std::string("cannot start the copy thread: ") + e.what());
+        }
     }
     F->numeric_ok = false;
     F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
