@@ -312,44 +312,203 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __double2hiint(d) hipcpu::d2hi(d)
 #define __hiloint2double(hi, lo) hipcpu::hilo2d((hi), (lo))
 
-// ---- the HIP runtime API the engine's host code uses; everything is synchronous
+// ---- the HIP runtime API the engine's host code uses.
+// HIPCPU_STREAMS (environment, read once):
+//   unset / "sync"   every call completes before it returns (the default: fastest, what the test suite runs)
+//   "lazy"           streams are queues: work runs only when somebody waits for it (hipStreamSynchronize,
+//                    hipEventSynchronize, hipFree; a hipStreamWaitEvent in a queue pulls the other stream up to the record
+//                    it captured).  A missing fence or synchronisation reads memory nobody has written yet.
+//   "greedy"         the same queues, but every wait first runs ALL other streams as far as they can go: work that a
+//                    reader should have been protected from (write-after-read across streams) has run before it reads.
+// Host memory is treated as pageable: a host-to-device copy takes its snapshot at the call, as the runtime does.
 #include <chrono>
 #include <cstdlib>
+#include <atomic>
+#include <deque>
+#include <memory>
+#include <tuple>
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-typedef void *hipStream_t;
-struct hipcpuEvent { std::chrono::steady_clock::time_point t; };
+namespace hipcpu {
+struct Stream;
+struct StreamOp { std::function<void()> fn; Stream *dep = nullptr; uint64_t dep_seq = 0; };
+struct Stream { std::deque<StreamOp> q; uint64_t enq = 0, done = 0; bool running = false; };
+inline int stream_mode()
+{
+    static const int m = [] {
+        const char *e = std::getenv("HIPCPU_STREAMS");
+        if (!e || !*e || !std::strcmp(e, "sync")) return 0;
+        if (!std::strcmp(e, "lazy")) return 1;
+        if (!std::strcmp(e, "greedy")) return 2;
+        std::abort();
+    }();
+    return m;
+}
+inline std::recursive_mutex &rt_mu() { static std::recursive_mutex m; return m; }
+// threads that are trying to get the lock: a thread that works through a queue lets them in between two operations (a
+// plain unlock/lock pair would win the mutex back before a sleeping waiter has woken up)
+inline std::atomic<int> &rt_waiters() { static std::atomic<int> n{0}; return n; }
+struct RtLock {
+    RtLock() { rt_waiters()++; rt_mu().lock(); rt_waiters()--; }
+    ~RtLock() { rt_mu().unlock(); }
+    RtLock(const RtLock &) = delete;
+};
+inline std::vector<Stream *> &all_streams() { static std::vector<Stream *> v; return v; }    // never shrinks: an event may name a destroyed stream
+inline void run_until(Stream *s, uint64_t seq)
+{
+    while (s->done < seq && !s->q.empty()) {
+        if (s->running) std::abort();       // a cycle of waits: the program would hang on the device too
+        StreamOp op = std::move(s->q.front());
+        s->q.pop_front();
+        s->running = true;
+        if (op.dep) run_until(op.dep, op.dep_seq);
+        if (op.fn) op.fn();
+        s->running = false;
+        s->done++;
+    }
+}
+inline void run_all_but(Stream *keep)
+{
+    for (size_t i = 0; i < all_streams().size(); i++) {
+        Stream *s = all_streams()[i];
+        if (s != keep && !s->running) run_until(s, s->enq);
+    }
+}
+// called WITHOUT the lock: one queued operation at a time under it, so that another host thread (a copy thread, another
+// rank) gets in between two operations -- as it would while a device works through its queue
+inline void wait_for(Stream *s, uint64_t seq)
+{
+    if (!s) return;
+    if (stream_mode() == 2) { RtLock lk; run_all_but(s); }
+    for (;;) {
+        {
+            RtLock lk;
+            if (s->done >= seq || s->q.empty()) return;
+            run_until(s, s->done + 1);
+        }
+        for (int spin = 0; spin < 200 && rt_waiters().load() > 0; spin++) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+inline void push(Stream *s, std::function<void()> fn, Stream *dep = nullptr, uint64_t dep_seq = 0)
+{
+    StreamOp op; op.fn = std::move(fn); op.dep = dep; op.dep_seq = dep_seq;
+    s->q.push_back(std::move(op));
+    s->enq++;
+}
+}  // namespace hipcpu
+typedef hipcpu::Stream *hipStream_t;
+struct hipcpuEvent { std::chrono::steady_clock::time_point t; hipcpu::Stream *s = nullptr; uint64_t seq = 0; };
 typedef hipcpuEvent *hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount = 1; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+#define HIPCPU_LOCK hipcpu::RtLock hipcpu_lk_
+// a null stream handle means "right now" (the engine creates its streams non-blocking: nothing orders them against it)
+#define HIPCPU_DEFER(s) (hipcpu::stream_mode() != 0 && (s) != nullptr)
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "hipcpu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::strcpy(p->gcnArchName, "gfx950:cpu-emulation"); return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
-inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (void *)1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int)
+{
+    HIPCPU_LOCK;
+    *s = new hipcpu::Stream;
+    hipcpu::all_streams().push_back(*s);
+    return hipSuccess;
+}
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreateWithPriority(s, 0, 0); }
-inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t s)
+{
+    if (hipcpu::stream_mode() == 0 || !s) return hipSuccess;
+    uint64_t upto;
+    { HIPCPU_LOCK; upto = s->enq; }
+    hipcpu::wait_for(s, upto);
+    return hipSuccess;
+}
+inline hipError_t hipDeviceSynchronize()
+{
+    if (hipcpu::stream_mode() == 0) return hipSuccess;
+    HIPCPU_LOCK;
+    hipcpu::run_all_but(nullptr);
+    return hipSuccess;
+}
+// the stream's work completes, the object stays (an event may still name it)
+inline hipError_t hipStreamDestroy(hipStream_t s) { return hipStreamSynchronize(s); }
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    if (!HIPCPU_DEFER(s)) {
+        if (hipcpu::stream_mode() != 0 && e->s) hipcpu::wait_for(e->s, e->seq);
+        return hipSuccess;
+    }
+    HIPCPU_LOCK;
+    if (e->s) hipcpu::push(s, nullptr, e->s, e->seq);       // the record made so far; a never-recorded event is complete
+    return hipSuccess;
+}
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipcpuEvent; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
-inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t e)
+{
+    if (hipcpu::stream_mode() == 0 || !e->s) return hipSuccess;
+    hipcpu::wait_for(e->s, e->seq);
+    return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) { (void)hipEventSynchronize(e); delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr)
+{
+    if (!HIPCPU_DEFER(s)) { e->t = std::chrono::steady_clock::now(); e->s = nullptr; return hipSuccess; }
+    HIPCPU_LOCK;
+    hipcpu::push(s, [e] { e->t = std::chrono::steady_clock::now(); });
+    e->s = s;
+    e->seq = s->enq;
+    return hipSuccess;
+}
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
-{ *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
+{
+    (void)hipEventSynchronize(a);
+    (void)hipEventSynchronize(b);
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
 inline hipError_t hipMalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p) { (void)hipDeviceSynchronize(); std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
-inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t)
-{ for (size_t r = 0; r < h; r++) std::memcpy((char *)d + r * dp, (const char *)s + r * sp, w); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st)
+{
+    if (!HIPCPU_DEFER(st)) return hipMemcpy(d, s, n, k);
+    HIPCPU_LOCK;
+    if (k == hipMemcpyHostToDevice) {
+        auto snap = std::make_shared<std::vector<char>>((const char *)s, (const char *)s + n);
+        hipcpu::push(st, [d, snap] { std::memcpy(d, snap->data(), snap->size()); });
+    } else {
+        hipcpu::push(st, [d, s, n] { std::memcpy(d, s, n); });
+    }
+    return hipSuccess;
+}
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t st)
+{
+    auto rows = [=](const char *src, size_t spitch) { for (size_t r = 0; r < h; r++) std::memcpy((char *)d + r * dp, src + r * spitch, w); };
+    if (!HIPCPU_DEFER(st)) { rows((const char *)s, sp); return hipSuccess; }
+    HIPCPU_LOCK;
+    if (k == hipMemcpyHostToDevice) {
+        auto snap = std::make_shared<std::vector<char>>(w * h);
+        for (size_t r = 0; r < h; r++) std::memcpy(snap->data() + r * w, (const char *)s + r * sp, w);
+        hipcpu::push(st, [rows, snap, w] { rows(snap->data(), w); });
+    } else {
+        hipcpu::push(st, [rows, s, sp] { rows((const char *)s, sp); });
+    }
+    return hipSuccess;
+}
 inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st)
+{
+    if (!HIPCPU_DEFER(st)) return hipMemset(d, v, n);
+    HIPCPU_LOCK;
+    hipcpu::push(st, [d, v, n] { std::memset(d, v, n); });
+    return hipSuccess;
+}
 namespace hipcpu {
 template <class F> void launch_dims(dim3 g, dim3 b, F call)
 {
@@ -359,6 +518,14 @@ template <class F> void launch_dims(dim3 g, dim3 b, F call)
     if (g.x == 0 || g.y == 0) return;
     launch((int64_t)g.x, b.x, call, g.y);
 }
+// the arguments are evaluated at the launch, as on the device; the kernel runs now (sync) or when the stream gets there
+template <class K, class... A> void enqueue_kernel(Stream *st, dim3 g, dim3 b, K kernel, A... args)
+{
+    if (!HIPCPU_DEFER(st)) { launch_dims(g, b, [&] { kernel(args...); }); return; }
+    HIPCPU_LOCK;
+    auto tup = std::make_tuple(args...);
+    push(st, [g, b, kernel, tup] { launch_dims(g, b, [&] { std::apply(kernel, tup); }); });
+}
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipcpu::launch_dims(dim3(grid), dim3(block), [&] { (kernel)(__VA_ARGS__); })
+    hipcpu::enqueue_kernel((hipStream_t)(stream), dim3(grid), dim3(block), (kernel), __VA_ARGS__)

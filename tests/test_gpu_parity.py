@@ -831,6 +831,9 @@ def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
         for _ in range(2):
             st = L.numeric(beta=g["beta"])
             want = L.Lx().copy()
+            # leave ANOTHER factor on the device: a chunk that left before it was recomputed must not look right
+            L.numeric(beta=g["beta"] + 0.75)
+            assert not np.array_equal(L.Lx().view(np.float64), want.view(np.float64))
             st2, got = L.numeric_host(beta=g["beta"])
             assert st == st2 == g["status"] and L.minor == g["minor"]
             assert np.array_equal(got.view(np.float64), want.view(np.float64))
