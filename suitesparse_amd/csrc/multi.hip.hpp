@@ -39,6 +39,11 @@ Rccl &rccl()
 {
     static Rccl R;
     if (R.lib || !R.why.empty()) return R;
+    // MI355_RCCL_LIB: the library to bind, by path (a site's own build of RCCL; the tests' stand-in)
+    if (const char *path = getenv("MI355_RCCL_LIB")) {
+        R.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) { R.why = std::string("MI355_RCCL_LIB: ") + (dlerror() ? dlerror() : "?"); return R; }
+    }
     // the copy this process already holds first (PyTorch ships its own): one RCCL per process
     const char *names[] = {"librccl.so", "librccl.so.1"};
     for (const char *nm : names) if (!R.lib) R.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

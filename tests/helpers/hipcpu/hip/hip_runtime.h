@@ -332,7 +332,7 @@ enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 namespace hipcpu {
 struct Stream;
-struct StreamOp { std::function<void()> fn; Stream *dep = nullptr; uint64_t dep_seq = 0; };
+struct StreamOp { std::function<void()> fn; Stream *dep = nullptr; uint64_t dep_seq = 0; std::function<bool()> ready; };
 struct Stream { std::deque<StreamOp> q; uint64_t enq = 0, done = 0; bool running = false; };
 inline int stream_mode()
 {
@@ -355,25 +355,39 @@ struct RtLock {
     RtLock(const RtLock &) = delete;
 };
 inline std::vector<Stream *> &all_streams() { static std::vector<Stream *> v; return v; }    // never shrinks: an event may name a destroyed stream
-inline void run_until(Stream *s, uint64_t seq)
+// run s until `seq` of its operations are done (lock held).  false: it cannot get there yet -- an operation waits for
+// something another host thread has still to enqueue (a collective whose peers have not issued it); the caller lets go
+// of the lock and tries again
+inline bool run_until(Stream *s, uint64_t seq)
 {
     while (s->done < seq && !s->q.empty()) {
-        if (s->running) std::abort();       // a cycle of waits: the program would hang on the device too
+        if (s->running) return false;       // somebody is inside this stream's head operation (a collective polling its peers)
+        s->running = true;
+        bool ok = true;
+        {
+            StreamOp &op = s->q.front();
+            if (op.dep) ok = run_until(op.dep, op.dep_seq);
+            if (ok && op.ready) ok = op.ready();
+        }
+        if (!ok) { s->running = false; return false; }
         StreamOp op = std::move(s->q.front());
         s->q.pop_front();
-        s->running = true;
-        if (op.dep) run_until(op.dep, op.dep_seq);
         if (op.fn) op.fn();
         s->running = false;
         s->done++;
     }
+    return true;
 }
 inline void run_all_but(Stream *keep)
 {
     for (size_t i = 0; i < all_streams().size(); i++) {
         Stream *s = all_streams()[i];
-        if (s != keep && !s->running) run_until(s, s->enq);
+        if (s != keep && !s->running) (void)run_until(s, s->enq);
     }
+}
+inline void let_others_in()
+{
+    for (int spin = 0; spin < 200 && rt_waiters().load() > 0; spin++) std::this_thread::sleep_for(std::chrono::microseconds(20));
 }
 // called WITHOUT the lock: one queued operation at a time under it, so that another host thread (a copy thread, another
 // rank) gets in between two operations -- as it would while a device works through its queue
@@ -382,17 +396,40 @@ inline void wait_for(Stream *s, uint64_t seq)
     if (!s) return;
     if (stream_mode() == 2) { RtLock lk; run_all_but(s); }
     for (;;) {
+        bool moved;
         {
             RtLock lk;
             if (s->done >= seq || s->q.empty()) return;
-            run_until(s, s->done + 1);
+            moved = run_until(s, s->done + 1);
         }
-        for (int spin = 0; spin < 200 && rt_waiters().load() > 0; spin++) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (moved) let_others_in();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
-inline void push(Stream *s, std::function<void()> fn, Stream *dep = nullptr, uint64_t dep_seq = 0)
+// hipDeviceSynchronize, hipFree: every stream of THIS device empty.  With one host thread per rank (tests) all ranks
+// share the emulated device, so "this device" = the streams the calling thread created; waiting for a peer's streams
+// would wait for collectives the caller itself has still to issue
+inline std::vector<Stream *> &my_streams() { static thread_local std::vector<Stream *> v; return v; }
+inline void wait_for_all()
 {
-    StreamOp op; op.fn = std::move(fn); op.dep = dep; op.dep_seq = dep_seq;
+    for (;;) {
+        bool empty = true;
+        {
+            RtLock lk;
+            if (stream_mode() == 2) run_all_but(nullptr);
+            for (Stream *s : my_streams()) {
+                if (!s->running) (void)run_until(s, s->enq);
+                empty = empty && s->q.empty();
+            }
+        }
+        if (empty) return;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+inline void push(Stream *s, std::function<void()> fn, Stream *dep = nullptr, uint64_t dep_seq = 0,
+                 std::function<bool()> ready = nullptr)
+{
+    StreamOp op; op.fn = std::move(fn); op.dep = dep; op.dep_seq = dep_seq; op.ready = std::move(ready);
     s->q.push_back(std::move(op));
     s->enq++;
 }
@@ -417,6 +454,7 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int)
     HIPCPU_LOCK;
     *s = new hipcpu::Stream;
     hipcpu::all_streams().push_back(*s);
+    hipcpu::my_streams().push_back(*s);
     return hipSuccess;
 }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreateWithPriority(s, 0, 0); }
@@ -431,8 +469,7 @@ inline hipError_t hipStreamSynchronize(hipStream_t s)
 inline hipError_t hipDeviceSynchronize()
 {
     if (hipcpu::stream_mode() == 0) return hipSuccess;
-    HIPCPU_LOCK;
-    hipcpu::run_all_but(nullptr);
+    hipcpu::wait_for_all();
     return hipSuccess;
 }
 // the stream's work completes, the object stays (an event may still name it)
@@ -529,3 +566,126 @@ template <class K, class... A> void enqueue_kernel(Stream *st, dim3 g, dim3 b, K
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipcpu::enqueue_kernel((hipStream_t)(stream), dim3(grid), dim3(block), (kernel), __VA_ARGS__)
+
+#ifdef HIPCPU_FAKE_RCCL
+// ---- a stand-in for librccl between THREADS of one process (one thread = one rank, tests/test_multi_abi.py): the nine
+// entry points the engine binds (suitesparse_amd/csrc/multi.hip.hpp), exported from the CPU build of the engine so that
+// MI355_RCCL_LIB can point the engine's loader at it.  A collective is an operation in the stream it was issued to; it
+// can run when every rank has ISSUED its matching call and every peer's stream has done everything in front of it; the
+// first rank whose stream gets there moves the data for all.  Calls that do not match (kind, count, type, root) abort:
+// on the device they would hang or corrupt.
+#include <map>
+#include <string>
+namespace hipcpu {
+struct FakeCall { bool have = false; int kind = 0; const void *send = nullptr; void *recv = nullptr; size_t count = 0;
+                  int dtype = 0, op = 0, root = 0; Stream *st = nullptr; uint64_t seq = 0; };
+struct FakeGroup { int world = 0, joined = 0; std::vector<std::vector<FakeCall>> slot; std::vector<char> done; };
+struct FakeComm { FakeGroup *g; int rank; size_t issued = 0; };
+inline std::map<std::string, FakeGroup *> &fake_groups() { static std::map<std::string, FakeGroup *> m; return m; }
+inline bool fake_ready(FakeGroup *g, size_t k, int r)
+{
+    if (g->done[k]) return true;
+    for (int p = 0; p < g->world; p++) if (!g->slot[k][(size_t)p].have) return false;
+    const FakeCall &me = g->slot[k][(size_t)r];
+    for (int p = 0; p < g->world; p++) {
+        const FakeCall &c = g->slot[k][(size_t)p];
+        if (c.kind != me.kind || c.count != me.count || c.dtype != me.dtype || c.op != me.op || c.root != me.root) {
+            fprintf(stderr, "fake rccl: collective %zu does not match between ranks %d and %d\n", k, r, p);
+            std::abort();
+        }
+        if (p != r && c.st && stream_mode() != 0 && !run_until(c.st, c.seq - 1)) return false;
+    }
+    return true;
+}
+template <class T> void fake_combine(FakeGroup *g, size_t k)
+{
+    const FakeCall &c0 = g->slot[k][0];
+    std::vector<T> acc(c0.count);
+    if (c0.kind == 1) {
+        const T *src = (const T *)g->slot[k][(size_t)c0.root].send;
+        acc.assign(src, src + c0.count);
+    } else {
+        for (int p = 0; p < g->world; p++) {
+            const T *src = (const T *)g->slot[k][(size_t)p].send;
+            for (size_t i = 0; i < c0.count; i++)
+                acc[i] = p == 0 ? src[i] : (c0.op == 3 ? std::min(acc[i], src[i]) : acc[i] + src[i]);
+        }
+    }
+    for (int p = 0; p < g->world; p++)
+        if (c0.kind != 0 || p == c0.root) std::memcpy(g->slot[k][(size_t)p].recv, acc.data(), c0.count * sizeof(T));
+}
+inline void fake_run(FakeGroup *g, size_t k)
+{
+    if (g->done[k]) return;
+    if (g->slot[k][0].dtype == 8) fake_combine<double>(g, k);
+    else if (g->slot[k][0].dtype == 4) fake_combine<int64_t>(g, k);
+    else std::abort();
+    g->done[k] = 1;
+}
+inline int fake_collective(int kind, const void *send, void *recv, size_t count, int dtype, int op, int root, void *comm, Stream *st)
+{
+    FakeComm *c = (FakeComm *)comm;
+    FakeGroup *g = c->g;
+    size_t k;
+    const int r = c->rank;
+    {
+        RtLock lk;
+        k = c->issued++;
+        if (g->slot.size() <= k) { g->slot.resize(k + 1, std::vector<FakeCall>((size_t)g->world)); g->done.resize(k + 1, 0); }
+        FakeCall &f = g->slot[k][(size_t)r];
+        f.have = true; f.kind = kind; f.send = send; f.recv = recv; f.count = count; f.dtype = dtype; f.op = op; f.root = root;
+        if (HIPCPU_DEFER(st)) {
+            f.st = st; f.seq = st->enq + 1;
+            push(st, [g, k] { fake_run(g, k); }, nullptr, 0, [g, k, r] { return fake_ready(g, k, r); });
+            return 0;
+        }
+    }
+    for (;;) {                                   // synchronous streams: the call returns when the collective is done
+        {
+            RtLock lk;
+            if (fake_ready(g, k, r)) { fake_run(g, k); return 0; }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+}  // namespace hipcpu
+struct hipcpuRcclId { char internal[128]; };
+extern "C" {
+inline __attribute__((used, visibility("default"))) int ncclGetUniqueId(hipcpuRcclId *id)
+{
+    static std::atomic<uint64_t> next{1};
+    std::memset(id->internal, 0, sizeof id->internal);
+    const uint64_t v = next++;
+    std::memcpy(id->internal, &v, sizeof v);
+    return 0;
+}
+inline __attribute__((used, visibility("default"))) int ncclCommInitRank(void **comm, int nranks, hipcpuRcclId id, int rank)
+{
+    hipcpu::FakeGroup *g;
+    {
+        hipcpu::RtLock lk;
+        hipcpu::FakeGroup *&slot = hipcpu::fake_groups()[std::string(id.internal, sizeof id.internal)];
+        if (!slot) { slot = new hipcpu::FakeGroup; slot->world = nranks; }
+        g = slot;
+        if (g->world != nranks || rank < 0 || rank >= nranks) return 4;     // ncclInvalidArgument
+        g->joined++;
+    }
+    for (;;) {                                   // like the real call: returns when every rank has joined
+        { hipcpu::RtLock lk; if (g->joined >= g->world) break; }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    *comm = new hipcpu::FakeComm{g, rank, 0};
+    return 0;
+}
+inline __attribute__((used, visibility("default"))) int ncclCommDestroy(void *comm) { delete (hipcpu::FakeComm *)comm; return 0; }
+inline __attribute__((used, visibility("default"))) int ncclReduce(const void *s, void *r, size_t n, int dt, int op, int root, void *comm, hipStream_t st)
+{ return hipcpu::fake_collective(0, s, r, n, dt, op, root, comm, st); }
+inline __attribute__((used, visibility("default"))) int ncclBroadcast(const void *s, void *r, size_t n, int dt, int root, void *comm, hipStream_t st)
+{ return hipcpu::fake_collective(1, s, r, n, dt, 0, root, comm, st); }
+inline __attribute__((used, visibility("default"))) int ncclAllReduce(const void *s, void *r, size_t n, int dt, int op, void *comm, hipStream_t st)
+{ return hipcpu::fake_collective(2, s, r, n, dt, op, 0, comm, st); }
+inline __attribute__((used, visibility("default"))) int ncclGroupStart() { return 0; }
+inline __attribute__((used, visibility("default"))) int ncclGroupEnd() { return 0; }
+inline __attribute__((used, visibility("default"))) const char *ncclGetErrorString(int) { return "fake rccl error"; }
+}
+#endif  // HIPCPU_FAKE_RCCL

@@ -8,8 +8,13 @@ queues (tests/helpers/hipcpu/hip/hip_runtime.h, HIPCPU_STREAMS):
   greedy  every wait first runs all OTHER streams as far as they can go -- work a reader should have been protected
           from has already run when it reads.
 
+The RCCL path of the N-rank driver runs here too: the CPU build exports a stand-in for librccl (collectives between
+threads, executed as operations of the emulated streams), so the event fences between the compute and the communication
+stream are exercised -- without either of its two hipStreamWaitEvent calls the factor is wrong under "lazy" (mutations;
+invisible with synchronous streams).
+
 The default suite runs with synchronous streams (fast); here a subset that exercises every stream the engine owns
-(compute, side, copy; the fences of the N-rank driver) is rerun in both modes, each in a process of its own (the mode is
+(compute, side, copy, communication) is rerun in both modes, each in a process of its own (the mode is
 read once per process).  The whole emulator suite under both modes: profiles/r02_asan_cpuemu.txt."""
 import os
 import subprocess
@@ -20,8 +25,9 @@ import pytest
 from conftest import ROOT
 
 SUBSET = ["tests/test_abi_on_cpu.py", "tests/test_multi_abi.py", "-k",
-          "(numeric_host and (lap2d_16 or tcov)) or test_solve2_with_permutation_all_systems or test_blas_timer "
-          "or (threads_as_ranks and (lap3d-4-2 or lap2d-16-4)) or (wide_top and 2-True-1-1-False)"]
+          "(numeric_host and (lap2d_16_metis or tcov)) or test_solve2_with_permutation_all_systems or test_blas_timer "
+          "or (threads_as_ranks and (lap3d-4-2 or lap2d-16-4)) or (wide_top and 2-True-1-1-False) "
+          "or (rccl_stand_in and (lap3d-6-3 or lap3d-4-2 or lap3d-12-2))"]
 
 
 @pytest.mark.parametrize("mode", ["lazy", "greedy"])

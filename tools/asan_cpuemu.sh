@@ -15,7 +15,7 @@ mkdir -p /tmp/asan_keep && cp $H/libmi355_cpuemu.so $H/libsched_emu.so /tmp/asan
 restore() { cp /tmp/asan_keep/libmi355_cpuemu.so /tmp/asan_keep/libsched_emu.so $H/; }
 trap restore EXIT
 C=$R/suitesparse_amd/csrc
-$CXX -x c++ -std=c++17 -O1 $SAN -w -pthread -fPIC -shared -I $H/hipcpu $C/engine.hip $C/schedule.cpp $C/symbolic.cpp -o $H/libmi355_cpuemu.so || exit 1
+$CXX -x c++ -std=c++17 -O1 $SAN -w -pthread -fPIC -shared -DHIPCPU_FAKE_RCCL -I $H/hipcpu $C/engine.hip $C/schedule.cpp $C/symbolic.cpp -o $H/libmi355_cpuemu.so || exit 1
 $CXX -std=c++17 -O1 $SAN -w -pthread -fPIC -shared -I $H/hipcpu $H/sched_emu.cpp $C/schedule.cpp -o $H/libsched_emu.so || exit 1
 cd $R
 # (tests/test_cholmod_dropin.py is left out: it loads a library with RTLD_DEEPBIND, which the sanitizer runtime refuses)
