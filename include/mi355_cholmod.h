@@ -235,7 +235,8 @@ int mi355_factor_reduce_plan(mi355_factor *handle, int64_t cap, int64_t *plan, i
 
 /* The collectives.  Either RCCL over xGMI -- stream-ordered: the engine's compute stream and the communicator's own
  * stream order each other with events, the host does not wait inside a factorization; librccl is bound at run time
- * (the copy the process already holds, else the system's), the engine has no link-time dependency on it --
+ * (the copy the process already holds, else the system's; the environment variable MI355_RCCL_LIB names another by
+ * path), the engine has no link-time dependency on it --
  *   mi355_rccl_unique_id(id)               on one rank: 128 bytes (ncclGetUniqueId) for the caller to hand to the others
  *   mi355_comm_create_rccl(id, rank, world, device, &c)     ncclCommInitRank on `device`
  *   mi355_comm_adopt_rccl(ncclComm, rank, world, device, &c)   an ncclComm_t the caller already has (not destroyed)
