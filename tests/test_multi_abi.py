@@ -393,10 +393,11 @@ def test_stream_ordered_driver_with_the_rccl_stand_in(engine, kind, size, world,
         engine.set_tuning(2, 256); engine.set_tuning(7, 1024)
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
+@pytest.mark.parametrize("seed,transport", [(k, "bus") for k in range(12)] + [(k, "rccl") for k in (1, 2, 3, 4, 6, 11)])
+def test_fuzz_of_the_c_driver_on_random_structures(engine, seed, transport):
     """random SPD structures (sparse graphs, chains, arrows, dense blocks) under a random permutation, 2-5 ranks, random
-    top mode, block width, look-ahead switch and transport (blocking = earliest, deferred = latest completion of every
+    top mode, block width, look-ahead switch and transport (transport = "rccl": the stream-ordered path with the stand-in
+    for librccl instead of the blocking callbacks) (blocking = earliest, deferred = latest completion of every
     collective), sometimes a negative pivot: every rank must end with the oracle's columns of L (or its truncated
     factor, minor and status), and the partitioned solves with its solution"""
     import test_fuzz_schedule as tf
@@ -424,10 +425,12 @@ def test_fuzz_of_the_c_driver_on_random_structures(engine, seed):
     want = None if spoil else port.super_solve(g, Lo, port.super_solve(g, Lo, B, lower=True), lower=False)
     engine.set_tuning(2, ob1); engine.set_tuning(7, ob); engine.set_tuning(16, lookahead)
     bus = Bus(world, defer)
+    box = IdBox(world)
     try:
         def body(rank):
             L = engine.SupernodalFactor(g)
-            comm = bus.comm(engine, rank)
+            # "rccl": the stream-ordered path with the stand-in for librccl (collectives as stream operations)
+            comm = bus.comm(engine, rank) if transport == "bus" else engine.Comm.rccl(rank, world, 0, box.exchange)
             owner, cnt = L.partition(rank, world, 1, dist_top)
             L.set_matrix(Sp, Si, Sx)
             st = L.numeric_multi(comm, 0.0, False)
