@@ -358,7 +358,9 @@ int mi355_factor_set_profile(mi355_factor *handle, int profile);
  *            16 ms in k_gemm128 launches (part of 1)      17 number of k_gemm128 launches
  *            18 useful flops of the tasks in k_gemm128    19 useful flops of the tasks in k_gemm64
  *            20 k_gemm128 tiles per factorization         21 k_gemm64 tiles
- *            22 useful k_gemm128 flops this handle executes (its share of a partition)   23 reserved */
+ *            22 useful k_gemm128 flops this handle executes (its share of a partition)
+ *            23 reduce channel (tuning key 19): launches of the top that the last mi355_factor_numeric_multi enqueued
+ *               before it had to wait for the last reduction (0: all reductions were awaited before the top) */
 int mi355_factor_get_stats(mi355_factor *handle, double *out24);
 
 /* Measured issue rate of bare v_mfma_f64_16x16x4_f64 on `device` (no counterpart in the reference;
@@ -386,7 +388,10 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * issued, so chain and broadcast overlap it; 0: the whole update first); key 17: a block of the distributed top is
  * broadcast in finished pieces of the first nested width (key 2: 256 columns) while its panel chain is still running
  * (default 1; 0: in one piece when it is complete); key 18: entries of Lx per chunk of mi355_factor_numeric_host
- * (default 32 Mi = 256 MB real; read when a handle copies for the first time); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * (default 32 Mi = 256 MB real; read when a handle copies for the first time); key 19: the reduce channel of the
+ * N-rank driver (read by mi355_comm_create_rccl / _adopt_rccl: a second communicator made with ncclCommSplit and a
+ * stream of its own for the sums of the top's ranges into their owners, awaited supernode by supernode where the top
+ * first touches them instead of all before the top; default 0 until it has been measured on xGMI); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

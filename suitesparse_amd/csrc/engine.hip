@@ -150,6 +150,7 @@ struct mi355_factor_s {
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_ev;            // one per chunk, created on first use
     double st_copy_early = 0;                   // entries copied before the last step had been enqueued
+    double st_red_overlap = 0;                  // reduce channel: launches of the top enqueued before the last reduction was awaited
 };
 
 namespace {
@@ -1749,6 +1750,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 16) tuning().dist_lookahead = value ? 1 : 0;
     else if (key == 17) tuning().dist_pieces = value ? 1 : 0;
     else if (key == 18) tuning().host_chunk = std::max(1, value);
+    else if (key == 19) tuning().dist_reduce_channel = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -1867,7 +1869,7 @@ int mi355_factor_get_stats(mi355_factor *F, double *out)
     out[11] = (double)S.relmap_size; out[12] = (double)S.dinv_size; out[13] = F->st_solve;
     out[14] = F->st_tiles; out[15] = F->st_copy_early;
     out[16] = F->st_big; out[17] = F->st_nbig; out[18] = S.flops_big; out[19] = S.flops_small;
-    out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[23] = 0;
+    out[20] = (double)S.tiles_big; out[21] = (double)S.tiles_small; out[23] = F->st_red_overlap;
     // useful k_gemm128 flops THIS handle executes per factorization: all of them, or its share of a partition
     out[22] = S.flops_big;
     if (F->part_local && F->part_top)

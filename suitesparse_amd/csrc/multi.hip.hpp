@@ -25,6 +25,7 @@ struct Rccl {
     int (*GetUniqueId)(RcclId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommSplit)(void *, int, int, void **, void *) = nullptr;     // optional (RCCL >= 2.18): the reduce channel
     int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -61,6 +62,7 @@ Rccl &rccl()
     R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
     R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
     R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    if (ok) R.CommSplit = (decltype(R.CommSplit))dlsym(R.lib, "ncclCommSplit");
     if (!ok) { R.lib = nullptr; }
     return R;
 }
@@ -76,6 +78,11 @@ struct mi355_comm_s {
     hipStream_t cs = nullptr;           // communication stream
     std::vector<hipEvent_t> ev;         // fences between the streams, reused round-robin
     size_t ev_next = 0;
+    // the reduce channel (tuning key 19): a second communicator (ncclCommSplit) on a stream of its own for the sums of the
+    // top's blocks into their owners, so that they run BESIDE the first broadcasts of the top instead of in front of them
+    void *nccl2 = nullptr;
+    hipStream_t cs2 = nullptr;
+    std::vector<hipEvent_t> red_ev;     // red_ev[g]: the reductions of issue group g (and all before it) are complete
     int64_t *dkey = nullptr;            // one int64 on the device (the agreement on the status)
     int grouped = 0;
     // MI355_TRANSPORT_DEFER (blocking transport): collectives are queued and run at the next point where the engine
@@ -554,6 +561,12 @@ static int comm_rccl_finish(mi355_comm_s *c, mi355_comm **out)
     HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));
     HIP_TRY(hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, phi));
     HIP_TRY(hipMalloc((void **)&c->dkey, sizeof(int64_t)));
+    if (tuning().dist_reduce_channel && c->world > 1) {
+        // collective: every rank makes the same call here (the tuning is process-wide and set before the communicator)
+        if (!rccl().CommSplit) return fail(MI355_NOT_INSTALLED, "tuning key 19 asks for a reduce channel, but this librccl has no ncclCommSplit");
+        RCCL_TRY(rccl().CommSplit(c->nccl, 0, c->rank, &c->nccl2, nullptr));
+        HIP_TRY(hipStreamCreateWithPriority(&c->cs2, hipStreamNonBlocking, phi));
+    }
     *out = c;
     return MI355_OK;
 }
@@ -606,11 +619,15 @@ int mi355_comm_free(mi355_comm *c)
     if (c->stream_ordered) {
         (void)hipSetDevice(c->device);
         if (c->cs) (void)hipStreamSynchronize(c->cs);
+        if (c->cs2) (void)hipStreamSynchronize(c->cs2);
+        if (c->nccl2 && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl2);
         if (c->own_nccl && c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
+        if (c->cs2) (void)hipStreamDestroy(c->cs2);
         if (c->cs) (void)hipStreamDestroy(c->cs);
         if (c->dkey) (void)hipFree(c->dkey);
     }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->red_ev) (void)hipEventDestroy(e);
     delete c;
     return MI355_OK;
 }
@@ -645,7 +662,15 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
         const Schedule &dsc = F->part_dist->sched;
         const int64_t nb = (int64_t)dsc.bcasts.size();
         // ---- own subtrees; every block of the top is summed into its owner as soon as this rank's last
-        //      contribution to it is enqueued (the reductions run beside the rest of the subtree work)
+        //      contribution to it is enqueued (the reductions run beside the rest of the subtree work).
+        //      With a reduce channel (tuning key 19) they go to the second communicator on its own stream, in issue
+        //      groups that also end where the next block belongs to another top supernode, each followed by an event
+        const bool chan2 = c->stream_ordered && c->nccl2 != nullptr;
+        F->st_red_overlap = 0;
+        void *rcomm = chan2 ? c->nccl2 : c->nccl;
+        hipStream_t rstream = chan2 ? c->cs2 : c->cs;
+        std::vector<int64_t> group_of((size_t)nb, -1);      // issue group of the reduction of each range of the plan
+        int64_t ngroups = 0;
         int64_t pos = 0;
         bool init = true;
         size_t i = 0;
@@ -657,24 +682,84 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
                 pos = need;
                 init = false;
             }
-            rc = fence_to_comm(F, c);
-            if (rc) return rc;
-            rc = c_group_begin(c);
-            if (rc) return rc;
-            for (; i < F->reduce_plan.size() && F->reduce_plan[i].ready_step == need; i++) {
-                const BcastPoint &b = dsc.bcasts[(size_t)F->reduce_plan[i].k];
-                rc = c_reduce(c, F->Lx.p + b.lo * E, b.count * E, b.root);
-                if (rc) { (void)c_group_end(c); return rc; }
+            if (chan2) {
+                hipEvent_t e;
+                rc = comm_event(c, &e);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(e, F->stream));
+                HIP_TRY(hipStreamWaitEvent(c->cs2, e, 0));
+            } else {
+                rc = fence_to_comm(F, c);
+                if (rc) return rc;
             }
-            rc = c_group_end(c);
-            if (rc) return rc;
+            while (i < F->reduce_plan.size() && F->reduce_plan[i].ready_step == need) {
+                const int32_t s0 = dsc.bcasts[(size_t)F->reduce_plan[i].k].s;
+                rc = c_group_begin(c);
+                if (rc) return rc;
+                for (; i < F->reduce_plan.size() && F->reduce_plan[i].ready_step == need &&
+                       (!chan2 || dsc.bcasts[(size_t)F->reduce_plan[i].k].s == s0); i++) {
+                    const BcastPoint &b = dsc.bcasts[(size_t)F->reduce_plan[i].k];
+                    group_of[(size_t)F->reduce_plan[i].k] = ngroups;
+                    if (c->stream_ordered) {
+                        if (b.count > 0) {
+                            const int r_ = rccl().Reduce(F->Lx.p + b.lo * E, F->Lx.p + b.lo * E, (size_t)(b.count * E), RCCL_F64,
+                                                         RCCL_SUM, b.root, rcomm, rstream);
+                            if (r_ != 0) { (void)c_group_end(c); return fail(MI355_GPU_PROBLEM, "ncclReduce failed"); }
+                        }
+                    } else {
+                        rc = c_reduce(c, F->Lx.p + b.lo * E, b.count * E, b.root);
+                        if (rc) { (void)c_group_end(c); return rc; }
+                    }
+                }
+                rc = c_group_end(c);
+                if (rc) return rc;
+                if (chan2) {
+                    while ((int64_t)c->red_ev.size() <= ngroups) {
+                        hipEvent_t e;
+                        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        c->red_ev.push_back(e);
+                    }
+                    HIP_TRY(hipEventRecord(c->red_ev[(size_t)ngroups], c->cs2));
+                }
+                ngroups++;
+            }
         }
         if (pos < nloc || init) {
             rc = run_schedule(F, loc, S.n, beta_re, tm, F->asm_mask.p, init, pos, nloc);
             if (rc) return rc;
         }
-        rc = fence_to_compute(F, c);
-        if (rc) return rc;
+        // when must which reductions be complete?  Without a reduce channel: all of them, before the top starts.  With
+        // one: group g before the first launch of THIS rank's top schedule that touches a top supernode with a range in
+        // a group >= ... <= g, i.e. for every top supernode s the last group that holds one of its ranges, before the
+        // first launch that reads or writes s (the in-order channel completes the earlier groups with it)
+        std::vector<std::pair<int64_t, int64_t>> red_wait;      // (step of the top schedule, group), by step
+        if (chan2) {
+            std::vector<int64_t> gmax((size_t)S.nsuper, -1), touch((size_t)S.nsuper, INT64_MAX);
+            for (int64_t k = 0; k < nb; k++)
+                if (group_of[(size_t)k] >= 0) gmax[(size_t)dsc.bcasts[(size_t)k].s] = std::max(gmax[(size_t)dsc.bcasts[(size_t)k].s], group_of[(size_t)k]);
+            auto super_of = [&](int64_t off) { return (int64_t)(std::upper_bound(S.Lpx, S.Lpx + S.nsuper + 1, off) - S.Lpx) - 1; };
+            auto mark = [&](int64_t off, int64_t si) {
+                const int64_t s_ = super_of(off);
+                if (s_ >= 0 && s_ < S.nsuper) touch[(size_t)s_] = std::min(touch[(size_t)s_], si);
+            };
+            for (size_t si = 0; si < dsc.steps.size(); si++) {
+                const Step &st = dsc.steps[si];
+                for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                    if (st.kind == STEP_POTRF) { mark(dsc.potrf[(size_t)ti].a_off, (int64_t)si); continue; }
+                    const GemmTask &t = dsc.gemm[(size_t)ti];
+                    mark(t.a_off, (int64_t)si);
+                    if (t.mode != GEMM_OVERWRITE) mark(t.b_off, (int64_t)si);
+                    mark(t.c_off, (int64_t)si);
+                }
+            }
+            for (int64_t s_ = 0; s_ < S.nsuper; s_++)
+                if (gmax[(size_t)s_] >= 0)      // (a top supernode no launch of this rank touches: waited for at the end)
+                    red_wait.push_back({touch[(size_t)s_] == INT64_MAX ? (int64_t)dsc.steps.size() : touch[(size_t)s_], gmax[(size_t)s_]});
+            std::sort(red_wait.begin(), red_wait.end());
+        } else {
+            rc = fence_to_compute(F, c);
+            if (rc) return rc;
+        }
         // ---- the top, owner-computes: the launches between two broadcast points, then the finished blocks
         {
             const int64_t lo = F->part_local->sched.dinv_size, hi = dsc.dinv_size;
@@ -683,22 +768,51 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
         // every broadcast has an issue point (its block is finished) and a wait point (the first launch that reads the
         // block); between the two lie launches that do not need it (BcastPoint::wait_step: look-ahead)
         int64_t step0 = 0, k = 0, wait_at = -1;
+        size_t rw = 0;
+        int64_t red_done = -1;          // groups <= red_done have been waited for by the compute stream
+        // the compute stream waits for the reductions that the launches up to (not including) step `upto` need
+        auto wait_reductions = [&](int64_t upto) -> int {
+            int64_t g = red_done;
+            for (; rw < red_wait.size() && red_wait[rw].first <= upto; rw++) g = std::max(g, red_wait[rw].second);
+            if (g > red_done) {
+                HIP_TRY(hipStreamWaitEvent(F->stream, c->red_ev[(size_t)g], 0));
+                red_done = g;
+                F->st_red_overlap = (double)std::min<int64_t>(upto, (int64_t)dsc.steps.size());
+            }
+            return MI355_OK;
+        };
+        // run the top's launches [step0, upto), stopping where a reduction has to be waited for first
+        auto run_top = [&](int64_t upto) -> int {
+            while (step0 < upto) {
+                int r = wait_reductions(step0);
+                if (r) return r;
+                const int64_t stop = rw < red_wait.size() ? std::min(upto, std::max(red_wait[rw].first, step0 + 1)) : upto;
+                r = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, stop);
+                if (r) return r;
+                step0 = stop;
+            }
+            return MI355_OK;
+        };
         while (k < nb || wait_at >= 0) {
             const int64_t issue_at = k < nb ? dsc.bcasts[(size_t)k].step : INT64_MAX;
             if (wait_at >= 0 && wait_at <= issue_at) {
-                rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, wait_at);
+                rc = run_top(wait_at);
                 if (rc) return rc;
-                step0 = wait_at;
                 wait_at = -1;
                 rc = fence_to_compute(F, c);            // everything issued so far has arrived
                 if (rc) return rc;
                 continue;
             }
-            rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, issue_at);
+            rc = run_top(issue_at);
             if (rc) return rc;
-            step0 = issue_at;
             rc = fence_to_comm(F, c);
             if (rc) return rc;
+            if (chan2) {
+                // a range is broadcast into the copies that its reduction read: the broadcast channel waits for it
+                int64_t g = -1;
+                for (int64_t kk = k; kk < nb && dsc.bcasts[(size_t)kk].step == issue_at; kk++) g = std::max(g, group_of[(size_t)kk]);
+                if (g >= 0) HIP_TRY(hipStreamWaitEvent(c->cs, c->red_ev[(size_t)g], 0));
+            }
             rc = c_group_begin(c);
             if (rc) return rc;
             for (; k < nb && dsc.bcasts[(size_t)k].step == issue_at; k++) {
@@ -711,7 +825,9 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
             rc = c_group_end(c);
             if (rc) return rc;
         }
-        rc = run_schedule(F, *F->part_dist, 0, 0.0, tm, nullptr, false, step0, (int64_t)dsc.steps.size());
+        rc = run_top((int64_t)dsc.steps.size());
+        if (rc) return rc;
+        rc = wait_reductions(INT64_MAX);        // (ranges of top supernodes this rank never touches)
         if (rc) return rc;
     } else {
         // ---- replicated top: own subtrees, ONE sum of the top panels over the ranks, the whole top on every rank

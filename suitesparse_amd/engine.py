@@ -252,7 +252,7 @@ class Comm:
 STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches", "assembly_ms",
              "flops_update", "flops_panel", "bytes_assembly", "npairs", "nlevels", "relmap_entries",
              "dinv_entries", "solve_ms", "gemm_tiles", "copy_early_entries", "gemm128_ms", "gemm128_launches",
-             "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "flops_gemm128_here", "reserved3"]
+             "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "flops_gemm128_here", "reduce_overlap_launches"]
 
 
 class SupernodalFactor:

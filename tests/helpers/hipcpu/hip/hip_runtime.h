@@ -578,49 +578,67 @@ template <class K, class... A> void enqueue_kernel(Stream *st, dim3 g, dim3 b, K
 #include <string>
 namespace hipcpu {
 struct FakeCall { bool have = false; int kind = 0; const void *send = nullptr; void *recv = nullptr; size_t count = 0;
-                  int dtype = 0, op = 0, root = 0; Stream *st = nullptr; uint64_t seq = 0; };
-struct FakeGroup { int world = 0, joined = 0; std::vector<std::vector<FakeCall>> slot; std::vector<char> done; };
-struct FakeComm { FakeGroup *g; int rank; size_t issued = 0; };
+                  int dtype = 0, op = 0, root = 0; Stream *st = nullptr; uint64_t seq = 0;
+                  bool snapped = false, executed = false; std::vector<char> snap; };
+struct FakeGroup { int world = 0, joined = 0; std::vector<std::vector<FakeCall>> slot;
+                   std::vector<FakeGroup *> children; };         // ncclCommSplit: the n-th split of every rank meets in children[n]
+struct FakeComm { FakeGroup *g; int rank; size_t issued = 0; size_t splits = 0; };
 inline std::map<std::string, FakeGroup *> &fake_groups() { static std::map<std::string, FakeGroup *> m; return m; }
+inline size_t fake_width(int dtype) { if (dtype != 8 && dtype != 4) std::abort(); return 8; }
+// does rank r's call k need rank p's data?
+inline bool fake_needs(const FakeCall &me, int r, int p)
+{
+    if (me.kind == 0) return r == me.root;              // reduce: the root needs everybody's
+    if (me.kind == 1) return p == me.root;              // broadcast: everybody needs the root's
+    return true;                                        // all-reduce
+}
+// A rank's send buffer is READ when its stream stands in front of its call (by whoever gets there first: nothing of
+// that stream runs in between, so it is the data the rank itself would send); a rank's receive buffer is WRITTEN only
+// when its OWN stream runs the call -- the latest moment its ordering allows, so a launch that should have waited for the
+// collective and does not sees the old contents, whatever the other ranks' threads are doing.
 inline bool fake_ready(FakeGroup *g, size_t k, int r)
 {
-    if (g->done[k]) return true;
     for (int p = 0; p < g->world; p++) if (!g->slot[k][(size_t)p].have) return false;
     const FakeCall &me = g->slot[k][(size_t)r];
+    bool all = true;
     for (int p = 0; p < g->world; p++) {
-        const FakeCall &c = g->slot[k][(size_t)p];
+        FakeCall &c = g->slot[k][(size_t)p];
         if (c.kind != me.kind || c.count != me.count || c.dtype != me.dtype || c.op != me.op || c.root != me.root) {
             fprintf(stderr, "fake rccl: collective %zu does not match between ranks %d and %d\n", k, r, p);
             std::abort();
         }
-        if (p != r && c.st && stream_mode() != 0 && !run_until(c.st, c.seq - 1)) return false;
+        if (c.snapped || !(p == r || fake_needs(me, r, p))) continue;
+        const bool there = p == r || (c.st && stream_mode() != 0 && run_until(c.st, c.seq - 1));
+        if (!there) { all = false; continue; }
+        c.snap.assign((const char *)c.send, (const char *)c.send + c.count * fake_width(c.dtype));
+        c.snapped = true;
     }
-    return true;
+    return all;
 }
-template <class T> void fake_combine(FakeGroup *g, size_t k)
+template <class T> void fake_result(FakeGroup *g, size_t k, int r)
 {
-    const FakeCall &c0 = g->slot[k][0];
-    std::vector<T> acc(c0.count);
-    if (c0.kind == 1) {
-        const T *src = (const T *)g->slot[k][(size_t)c0.root].send;
-        acc.assign(src, src + c0.count);
+    FakeCall &me = g->slot[k][(size_t)r];
+    if (me.kind == 0 && r != me.root) return;           // a reduce leaves the other ranks' buffers as they are
+    std::vector<T> acc(me.count);
+    if (me.kind == 1) {
+        std::memcpy(acc.data(), g->slot[k][(size_t)me.root].snap.data(), me.count * sizeof(T));
     } else {
         for (int p = 0; p < g->world; p++) {
-            const T *src = (const T *)g->slot[k][(size_t)p].send;
-            for (size_t i = 0; i < c0.count; i++)
-                acc[i] = p == 0 ? src[i] : (c0.op == 3 ? std::min(acc[i], src[i]) : acc[i] + src[i]);
+            const T *src = (const T *)g->slot[k][(size_t)p].snap.data();
+            for (size_t i = 0; i < me.count; i++)
+                acc[i] = p == 0 ? src[i] : (me.op == 3 ? std::min(acc[i], src[i]) : acc[i] + src[i]);
         }
     }
-    for (int p = 0; p < g->world; p++)
-        if (c0.kind != 0 || p == c0.root) std::memcpy(g->slot[k][(size_t)p].recv, acc.data(), c0.count * sizeof(T));
+    std::memcpy(me.recv, acc.data(), me.count * sizeof(T));
 }
-inline void fake_run(FakeGroup *g, size_t k)
+inline void fake_run(FakeGroup *g, size_t k, int r)
 {
-    if (g->done[k]) return;
-    if (g->slot[k][0].dtype == 8) fake_combine<double>(g, k);
-    else if (g->slot[k][0].dtype == 4) fake_combine<int64_t>(g, k);
-    else std::abort();
-    g->done[k] = 1;
+    FakeCall &me = g->slot[k][(size_t)r];
+    if (me.dtype == 8) fake_result<double>(g, k, r); else fake_result<int64_t>(g, k, r);
+    me.executed = true;
+    bool all = true;
+    for (int p = 0; p < g->world; p++) all = all && g->slot[k][(size_t)p].executed;
+    if (all) for (int p = 0; p < g->world; p++) std::vector<char>().swap(g->slot[k][(size_t)p].snap);
 }
 inline int fake_collective(int kind, const void *send, void *recv, size_t count, int dtype, int op, int root, void *comm, Stream *st)
 {
@@ -631,19 +649,19 @@ inline int fake_collective(int kind, const void *send, void *recv, size_t count,
     {
         RtLock lk;
         k = c->issued++;
-        if (g->slot.size() <= k) { g->slot.resize(k + 1, std::vector<FakeCall>((size_t)g->world)); g->done.resize(k + 1, 0); }
+        if (g->slot.size() <= k) g->slot.resize(k + 1, std::vector<FakeCall>((size_t)g->world));
         FakeCall &f = g->slot[k][(size_t)r];
         f.have = true; f.kind = kind; f.send = send; f.recv = recv; f.count = count; f.dtype = dtype; f.op = op; f.root = root;
         if (HIPCPU_DEFER(st)) {
             f.st = st; f.seq = st->enq + 1;
-            push(st, [g, k] { fake_run(g, k); }, nullptr, 0, [g, k, r] { return fake_ready(g, k, r); });
+            push(st, [g, k, r] { fake_run(g, k, r); }, nullptr, 0, [g, k, r] { return fake_ready(g, k, r); });
             return 0;
         }
     }
     for (;;) {                                   // synchronous streams: the call returns when the collective is done
         {
             RtLock lk;
-            if (fake_ready(g, k, r)) { fake_run(g, k); return 0; }
+            if (fake_ready(g, k, r)) { fake_run(g, k, r); return 0; }
         }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
@@ -674,7 +692,28 @@ inline __attribute__((used, visibility("default"))) int ncclCommInitRank(void **
         { hipcpu::RtLock lk; if (g->joined >= g->world) break; }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
-    *comm = new hipcpu::FakeComm{g, rank, 0};
+    *comm = new hipcpu::FakeComm{g, rank, 0, 0};
+    return 0;
+}
+// (all ranks in one colour, key = rank: what the engine asks for)
+inline __attribute__((used, visibility("default"))) int ncclCommSplit(void *comm, int color, int key, void **newcomm, void *)
+{
+    hipcpu::FakeComm *c = (hipcpu::FakeComm *)comm;
+    if (color != 0 || key != c->rank) return 4;
+    hipcpu::FakeGroup *g;
+    {
+        hipcpu::RtLock lk;
+        const size_t n = c->splits++;
+        if (c->g->children.size() <= n) c->g->children.resize(n + 1, nullptr);
+        if (!c->g->children[n]) { c->g->children[n] = new hipcpu::FakeGroup; c->g->children[n]->world = c->g->world; }
+        g = c->g->children[n];
+        g->joined++;
+    }
+    for (;;) {
+        { hipcpu::RtLock lk; if (g->joined >= g->world) break; }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    *newcomm = new hipcpu::FakeComm{g, c->rank, 0, 0};
     return 0;
 }
 inline __attribute__((used, visibility("default"))) int ncclCommDestroy(void *comm) { delete (hipcpu::FakeComm *)comm; return 0; }

@@ -27,7 +27,7 @@ from conftest import ROOT
 SUBSET = ["tests/test_abi_on_cpu.py", "tests/test_multi_abi.py", "-k",
           "(numeric_host and (lap2d_16_metis or tcov)) or test_solve2_with_permutation_all_systems or test_blas_timer "
           "or (threads_as_ranks and (lap3d-4-2 or lap2d-16-4)) or (wide_top and 2-True-1-1-False) "
-          "or (rccl_stand_in and (lap3d-6-3 or lap3d-4-2 or lap3d-12-2)) or (fuzz and rccl)"]
+          "or (rccl_stand_in and (lap3d-6-3 or lap3d-4-2-True-True-64-1 or ob10-1)) or 1-rccl or 3-rccl"]
 
 
 @pytest.mark.parametrize("mode", ["lazy", "greedy"])
