@@ -804,7 +804,7 @@ def test_device_side_permutation_of_a_matrix_that_is_not_posdef(engine, name):
 def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
     """mi355_factor_numeric_host: L->x on the host filled chunk by chunk while the factorization runs (tuning key 18 =
     entries per chunk, small here so that a fixture has many chunks) must be what mi355_factor_numeric +
-    mi355_factor_get_Lx give, bit for bit -- positive definite or not (the failing case gets one plain copy after the
+    mi355_factor_get_Lx give (to rounding of the atomically added updates) -- positive definite or not (the failing case gets one plain copy after the
     replay) -- and on a refactorization; the plan tiles Lx, is ordered, and most chunks are ready before the last launch"""
     from conftest import load_golden, sym_of
     import scipy.sparse as sp
@@ -836,7 +836,9 @@ def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
             assert not np.array_equal(L.Lx().view(np.float64), want.view(np.float64))
             st2, got = L.numeric_host(beta=g["beta"])
             assert st == st2 == g["status"] and L.minor == g["minor"]
-            assert np.array_equal(got.view(np.float64), want.view(np.float64))
+            # (not bit for bit: the scatter updates of one level add with atomics, whose order differs from run to run on
+            # the device; a chunk that left too early would hold the other factor, which differs in the first digit)
+            assert np.array_equal(got == 0, want == 0) and relerr(got, want) < 1e-12
             assert relerr(got, g["Lx"]) < TOL_L
             early = L.stats()["copy_early_entries"]
             if st == 0 and len(plan) >= 4:

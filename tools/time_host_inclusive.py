@@ -38,7 +38,7 @@ def main():
     def host():
         got["st"], got["Lx"] = L.numeric_host()
     t_host = best(host)
-    assert got["st"] == 0 and np.array_equal(got["Lx"], ref)
+    assert got["st"] == 0 and float(np.max(np.abs(got["Lx"] - ref))) <= 1e-12 * float(np.max(np.abs(ref)))
     early = L.stats()["copy_early_entries"]
     res = dict(problem=f"lap3d {grid}", n=int(sym["n"]), fl=float(sym["fl"]), factor_GB=sym["xsize"] * 8e-9,
                resident_s=t_res, numeric_then_get_Lx_s=t_ser, numeric_host_s=t_host,
