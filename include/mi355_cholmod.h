@@ -134,6 +134,15 @@ int mi355_factor_host_copy_plan(mi355_factor *handle, int64_t cap, int64_t *plan
  * factor need not be copied to the host for it. */
 int mi355_factor_rcond(mi355_factor *handle, double *rcond);
 
+/* mi355_factor_rcond for callers that cannot allocate (code under HIP graph capture set-up, tight serving loops,
+ * harnesses that forbid hipMalloc): NO counterpart in the reference.  The same two-step reduction, but the per-workgroup
+ * partial results live in a 24 KB array that the library holds on every GPU for the life of the process, the result goes
+ * to a DEVICE double of the caller's (complete when the call returns), and the call allocates nothing on the host or the
+ * device.  Limit: 1024 partial triples -- always enough, a workgroup strides over more columns for n > 262 144 (a
+ * request beyond it would be refused with MI355_TOO_LARGE).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU race (mi355_factor_rcond does not have this restriction). */
+int mi355_factor_rcond_noalloc(mi355_factor *handle, double *rcond_dev);
+
 /* The resident supernodal factor as a packed, monotonic simplicial one (cholmod_change_factor to simplicial numeric:
  * super_num_to_simplicial_num, CHOLMOD/Utility/t_cholmod_change_factor.c:875-1065 and
  * t_cholmod_change_factor_3_template.c): Lp[n+1], Li[lnz], Lnz[n] from the symbolic structure,

@@ -1039,6 +1039,94 @@ int mi355_factor_rcond(mi355_factor *F, double *rcond)
     return MI355_OK;
 }
 
+}  // extern "C"
+
+// ---- mi355_factor_rcond_noalloc: the scratch of k_diag_minmax (one min / max / NaN triple per workgroup) lives in a
+// file-scope device array instead of a hipMalloc'ed buffer.  Every GPU holds its own copy of the array at its own address,
+// until the process ends.  Host code never uses the array's NAME as a pointer (on the host it is a stand-in, not a device
+// address): the address on each device comes from hipGetSymbolAddress, once per device, and `ptr` is what the kernels get.
+#define MI355_RCOND_SCRATCH_BLOCKS 1024
+static __device__ __align__(256) double scratch[3 * MI355_RCOND_SCRATCH_BLOCKS];       // 24 KB per GPU
+
+namespace {
+
+constexpr int MAX_SCRATCH_DEVICES = 64;
+double *g_scratch_ptr[MAX_SCRATCH_DEVICES] = {};
+std::mutex g_scratch_mu;
+
+// the address of `scratch` on `device` (which is current)
+int scratch_on_device(int device, double **out)
+{
+    if (device < 0 || device >= MAX_SCRATCH_DEVICES) return fail(MI355_INVALID, "device index beyond the scratch table");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        double *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(MI355_GPU_PROBLEM, "hipGetSymbolAddress returned no address for the scratch array");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return MI355_OK;
+}
+
+// the partial triples of `blocks` workgroups -> (min / max)^2, 0 if a NaN was seen; fixed != 0: that value as it is
+__global__ __launch_bounds__(256) void k_rcond_finish(int blocks, const double *__restrict__ part, double fixed, int use_fixed,
+                                                      double *__restrict__ out)
+{
+    __shared__ double smin[256], smax[256], snan[256];
+    double lo = INFINITY, hi = -INFINITY, bad = 0.0;
+    for (int b = (int)threadIdx.x; b < blocks; b += 256) {
+        lo = fmin(lo, part[3 * b]); hi = fmax(hi, part[3 * b + 1]); bad = fmax(bad, part[3 * b + 2]);
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi; snan[threadIdx.x] = bad;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + h]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + h]);
+            snan[threadIdx.x] = fmax(snan[threadIdx.x], snan[threadIdx.x + h]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double r = smin[0] / smax[0];
+        out[0] = use_fixed ? fixed : (snan[0] != 0.0 ? 0.0 : r * r);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_factor_rcond_noalloc(mi355_factor *F, double *rcond_dev)
+{
+    g_err.clear();
+    int rc = check_handle(F);
+    if (rc) return rc;
+    if (!rcond_dev) return fail(MI355_INVALID, "null rcond");
+    const Symbolic &S = F->sym;
+    if (S.n > 0 && !F->numeric_ok && !F->not_posdef) return fail(MI355_INVALID, "no numeric factor is resident");
+    double *ptr = nullptr;
+    rc = scratch_on_device(F->device, &ptr);
+    if (rc) return rc;
+    const int64_t want = S.n > 0 ? (S.n + 255) / 256 : 1;
+    const int blocks = (int)std::min<int64_t>(MI355_RCOND_SCRATCH_BLOCKS, want);        // a workgroup strides over more columns
+    if ((size_t)blocks * 3 * sizeof(double) > sizeof(double) * 3 * MI355_RCOND_SCRATCH_BLOCKS)
+        return fail(MI355_TOO_LARGE, "too large: the diagonal needs more partial results than the scratch array holds");
+    if (S.n == 0 || !F->numeric_ok) {
+        // cholmod_rcond.c:73-80: 1 for an empty matrix, 0 when the factorization stopped at a bad pivot
+        hipLaunchKernelGGL(k_rcond_finish, dim3(1), dim3(256), 0, F->stream, 0, ptr, S.n == 0 ? 1.0 : 0.0, 1, rcond_dev);
+    } else {
+        // every slot the second kernel reads is written by the first (blocks triples): nothing of an earlier call is seen
+        hipLaunchKernelGGL(k_diag_minmax, dim3((unsigned)blocks), dim3(256), 0, F->stream, S.n, F->E, F->dSupermap.p,
+                           F->dSuper.p, F->dLpi.p, F->dLpx.p, F->Lx.p, ptr);
+        hipLaunchKernelGGL(k_rcond_finish, dim3(1), dim3(256), 0, F->stream, blocks, ptr, 0.0, 0, rcond_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(F->stream));         // rcond_dev is the caller's: complete on return
+    return MI355_OK;
+}
+
 int mi355_super_numeric(mi355_factor *F, const int64_t *Ap, const int64_t *Ai, const int64_t *Anz,
                         const double *Ax, double beta_re, int quick_return_if_not_posdef,
                         double *Lx, int64_t *minor, int *status)

@@ -30,7 +30,7 @@ _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 EXPORTS = [
     "mi355_probe", "mi355_last_error", "mi355_factor_create", "mi355_factor_free",
     "mi355_factor_set_matrix", "mi355_factor_numeric", "mi355_factor_get_Lx",
-    "mi355_factor_numeric_host", "mi355_factor_host_copy_plan",
+    "mi355_factor_numeric_host", "mi355_factor_host_copy_plan", "mi355_factor_rcond_noalloc",
     "mi355_super_numeric", "mi355_super_lsolve", "mi355_super_ltsolve",
     "mi355_super_lsolve_dev", "mi355_super_ltsolve_dev", "mi355_factor_device_Lx",
     "mi355_factor_set_profile", "mi355_factor_get_stats", "mi355_debug_mfma_f64_rate",
@@ -315,6 +315,12 @@ class SupernodalFactor:
         f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _check(f(self._h, C.byref(out)))
         return out.value
+
+    def rcond_noalloc(self, out_dev_ptr):
+        """mi355_factor_rcond_noalloc: the result goes to the caller's device double at out_dev_ptr"""
+        f = lib().mi355_factor_rcond_noalloc
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self._h, C.c_void_p(int(out_dev_ptr))))
 
     def set_matrix_perm(self, Ap, Ai, Ax, Perm=None, Anz=None):
         """stage A itself (lower part, stype < 0) + L->Perm: S = tril(P A P') is placed by the assembly kernel"""

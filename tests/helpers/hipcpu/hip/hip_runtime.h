@@ -294,6 +294,8 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __align__(n) __attribute__((aligned(n)))
+#define HIP_SYMBOL(x) ((const void *)&(x))
 #define __shared__ static
 #ifndef __clang__
 #define ext_vector_type(n) vector_size((n) * 8)                // g++: no .x/.y swizzles (kernels_complex needs clang)
@@ -509,6 +511,7 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
+inline hipError_t hipGetSymbolAddress(void **p, const void *symbol) { *p = const_cast<void *>(symbol); return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void *p) { (void)hipDeviceSynchronize(); std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
