@@ -128,7 +128,8 @@ constexpr int32_t STEP_SIDE = 1, STEP_JOIN = 2;
 // four tasks per workgroup) instead of one workgroup per task.  The low levels of the tree are made of hundreds of
 // thousands of such tasks (2D 2000^2, level 0: 661 299 updates of a few entries each), where a launch is bound by
 // workgroup slots and the latency chain inside one workgroup, not by flops.  Tasks and tile table entries are the
-// ordinary ones (tile (0, 0) of a 64 x 64-tile task).  Off by default (tiny_max = 0) until measured on the device.
+// ordinary ones (tile (0, 0) of a 64 x 64-tile task).  On by default since round 2 (tiny_max = 2048 flops M*N*K: 2D 2000^2 27.8 -> 20.2 ms on the MI355X, 3D configs unchanged;
+// profiles/r02_tiny_classes.txt); 0 switches the classes off.
 constexpr int32_t STEP_TINY = 4;
 
 struct Symbolic {
@@ -216,7 +217,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 0; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -143,18 +143,18 @@ def test_unsym_fset_through_the_abi(engine, have_ref):
 def test_tiny_launch_classes_through_the_abi(engine, name, tiny_max):
     """tuning key 14 through the engine: the potrf order list upload, k_potrf16 (+ fused TRSM) / k_potrf64 with the order,
     k_gemm_tiny launches"""
-    import wip_tiny_tasks as w
+    import test_gpu_tiny_tasks as w
     w.test_tiny_launch_class_golden(engine, name, tiny_max)
 
 
 @pytest.mark.parametrize("n", [1, 5, 16, 17, 80])
 def test_small_dense_supernode_through_the_wave_potrf(engine, n):
-    import wip_tiny_tasks as w
+    import test_gpu_tiny_tasks as w
     w.test_small_dense_supernode_through_the_wave_potrf(engine, n)
 
 
 def test_wave_potrf_reports_the_first_bad_pivot(engine):
-    import wip_tiny_tasks as w
+    import test_gpu_tiny_tasks as w
     w.test_wave_potrf_reports_the_first_bad_pivot(engine)
 
 
@@ -283,7 +283,7 @@ def test_partitioned_factor_through_the_abi(engine, world, spoil, tiny_max):
         for x in Xs:
             assert relerr(x.numpy(), want) < 1e-9
     finally:
-        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(14, 0)
+        engine.set_tuning(2, 256); engine.set_tuning(7, 1024); engine.set_tuning(14, 2048)
 
 
 @pytest.mark.parametrize("kind,size", [("lap3d", 4), ("helm", 3)])
@@ -321,7 +321,7 @@ def test_random_structure_end_to_end_through_the_abi(engine, kind, n, seed, tiny
         X = L.solve(B, sys=0)
         L.close()
     finally:
-        engine.set_tuning(14, 0)
+        engine.set_tuning(14, 2048)
     assert np.abs(A @ X - B).max() <= 1e-12 * np.abs(B).max() * n
     for s in range(sym["nsuper"]):
         a, b = int(sym["Lpx"][s]), int(sym["Lpx"][s + 1])

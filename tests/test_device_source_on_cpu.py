@@ -28,7 +28,7 @@ def test_factorization_through_the_device_source(emu, name, tiny_max):  # noqa: 
     try:
         st, minor, Lx, _ = run_emu(emu, g)
     finally:
-        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 2048)
     assert (st, minor) == (g["status"], g["minor"])
     assert relerr(Lx, g["Lx"]) < 1e-12
     if st == 1:
@@ -53,7 +53,7 @@ def test_wave_potrf_source_one_host_thread_per_lane(emu, name):  # noqa: F811
             assert emu.emu_super_solve(0, *a, Lx, D, nrhs, X, n) == 0
             assert relerr(X.reshape(nrhs, n).T, g["Z"]) < 1e-8
     finally:
-        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 2048)
     assert (st, minor) == (g["status"], g["minor"])
     assert relerr(Lx, g["Lx"]) < 1e-12
     if st == 1:
@@ -68,7 +68,7 @@ def test_unsym_factorization_through_the_device_source(emu, name):  # noqa: F811
     try:
         st, minor, Lx = tu.emu_numeric_f(g)
     finally:
-        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 2048)
     assert (st, minor) == (g["status"], g["minor"])
     assert relerr(Lx, g["Lx"]) < 1e-11
 
@@ -383,7 +383,7 @@ def test_random_structures_through_the_device_kernels(emu, kind, n, seed, tiny_m
     try:
         st, minor, Lx, D = run_emu(emu, g)
     finally:
-        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(100, 0); emu.emu_set_tuning(14, 2048)
     assert (st, minor) == (so, mo) == (0, n)
     for s in range(g["nsuper"]):
         a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])

@@ -133,4 +133,4 @@ def test_random_structure_partition_bounds(emu, kind, n, seed, world):  # noqa: 
                                                 (owner < 0).astype(np.int8), r, world, msg, 300)
                 assert rc == 0, (r, rc, msg.value.decode())
     finally:
-        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 2048)

@@ -313,7 +313,7 @@ def test_reduce_to_owner_covers_the_top_panels(kind, size, world, ob2, tiny_max)
                     low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
                     assert relerr(got[low], want[low]) < 1e-11, (r, s)
     finally:
-        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(2, 256); emu.emu_set_tuning(7, 1024); emu.emu_set_tuning(14, 2048)
 
 
 def run_distributed_lockstep(runners, facs):

@@ -112,7 +112,7 @@ def test_tiny_launch_class(emu, name, tiny_max):
         rc = emu.emu_super_numeric(*a, g["Sp"], g["Si"], np.ascontiguousarray(g["Sx"], dtype=np.float64), g["beta"],
                                    0, Lx, D, minor, C.byref(st), stats)
     finally:
-        emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(14, 2048)
     assert rc == 0
     assert st.value == g["status"] and int(minor[0]) == g["minor"]
     assert relerr(Lx, g["Lx"]) < 1e-12
@@ -124,7 +124,7 @@ def test_tiny_launch_class(emu, name, tiny_max):
     try:
         assert emu.emu_schedule_classes(*a, cls) == 0
     finally:
-        emu.emu_set_tuning(14, 0)
+        emu.emu_set_tuning(14, 2048)
     assert cls[4] == 1
     nb = np.concatenate([np.minimum(64, w - np.arange(0, w, 64)) for w in np.diff(g["Super"])])
     if st.value == 0:

@@ -11,7 +11,7 @@ done
 timeout -k 10 240 python -u tools/time_host_inclusive.py 100 $O/host_inclusive_lap3d100.json > $O/host_inclusive.log 2>&1 || { tail -5 $O/host_inclusive.log; exit 1; }
 tail -1 $O/host_inclusive.log
 timeout -k 10 200 bash tools/solve_profile.sh 64 > $O/solve_nrhs64.txt 2>&1 || exit $?
-timeout -k 10 200 python -u -m pytest tests/wip_tiny_tasks.py -m gpu -x -q --timeout 120 --timeout-method thread > $O/wip_tiny.log 2>&1 || { tail -20 $O/wip_tiny.log; exit 1; }
+timeout -k 10 200 python -u -m pytest tests/test_gpu_tiny_tasks.py -m gpu -x -q --timeout 120 --timeout-method thread > $O/wip_tiny.log 2>&1 || { tail -20 $O/wip_tiny.log; exit 1; }
 for K in 0 256 2048 16384; do
     timeout -k 10 120 python -u bench.py --problem lap2d --steps 5 --warmup 2 --no-cpu --tune 14=$K > $O/bench_lap2d_tiny$K.json 2> $O/bench_lap2d_tiny$K.err || exit $?
     python3 -c "import json,sys; d=json.load(open('$O/bench_lap2d_tiny$K.json')); print('tiny_max', $K, d['ms_per_step'], 'ms', d['value'], 'GFLOP/s')"
