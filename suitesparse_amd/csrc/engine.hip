@@ -149,6 +149,11 @@ struct mi355_factor_s {
     std::vector<HostCopyChunk> copy_plan;
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_ev;            // one per chunk, created on first use
+    // lanes of the copy: a pinned staging buffer + a stream each (the DMA runs at PCIe rate into pinned memory; the lanes'
+    // host threads then move their pieces into the caller's pageable L->x in parallel)
+    std::vector<void *> lane_pin;
+    std::vector<hipStream_t> lane_stream;
+    size_t lane_bytes = 0;
     double st_copy_early = 0;                   // entries copied before the last step had been enqueued
     double st_red_overlap = 0;                  // reduce channel: launches of the top enqueued before the last reduction was awaited
 };
@@ -277,21 +282,26 @@ struct EventTimer {
 // then copies on the copy stream.  A blocking copy into pageable memory (L->x is cholmod_malloc'ed) therefore never
 // holds up the enqueueing of kernels.
 struct HostCopier {
-    struct Item { hipEvent_t ev; int64_t lo, hi; };
+    struct Item { hipEvent_t ev; int64_t lo, hi; };     // entries [lo, hi) of Lx, final once ev has completed
     mi355_factor_s *F;
     double *dst;
-    std::thread th;
+    std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Item> q;
     bool closed = false;
     hipError_t err = hipSuccess;
     size_t next = 0;            // next chunk of F->copy_plan to hand over (main thread)
-    HostCopier(mi355_factor_s *F_, double *dst_) : F(F_), dst(dst_) { th = std::thread([this] { run(); }); }
+    // lanes: threads that each own a pinned staging buffer and a stream of the handle (make_lanes)
+    HostCopier(mi355_factor_s *F_, double *dst_) : F(F_), dst(dst_)
+    {
+        for (size_t l = 0; l < F->lane_stream.size(); l++) th.emplace_back([this, l] { run(l); });
+    }
     ~HostCopier() { (void)finish(); }
-    void run()
+    void run(size_t lane)
     {
         hipError_t e = hipSetDevice(F->device);
+        const size_t E = (size_t)F->E;
         for (;;) {
             Item it;
             {
@@ -303,16 +313,27 @@ struct HostCopier {
             }
             if (e != hipSuccess) continue;      // keep draining so that finish() returns
             e = hipEventSynchronize(it.ev);
-            const size_t E = (size_t)F->E;
+            const size_t bytes = (size_t)(it.hi - it.lo) * E * sizeof(double);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(dst + (size_t)it.lo * E, F->Lx.p + (size_t)it.lo * E,
-                                   (size_t)(it.hi - it.lo) * E * sizeof(double), hipMemcpyDeviceToHost, F->copy_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(F->copy_stream);
+                e = hipMemcpyAsync(F->lane_pin[lane], F->Lx.p + (size_t)it.lo * E, bytes, hipMemcpyDeviceToHost, F->lane_stream[lane]);
+            if (e == hipSuccess) e = hipStreamSynchronize(F->lane_stream[lane]);
+            if (e == hipSuccess) memcpy(dst + (size_t)it.lo * E, F->lane_pin[lane], bytes);
         }
         std::lock_guard<std::mutex> lk(mu);
-        err = e;
+        if (e != hipSuccess) err = e;
     }
-    // main thread: chunk k is final on stream `st` from here on
+    // main thread: entries [lo, hi) are final on stream `st` from here on; they go to the lanes in pieces that fit a
+    // staging buffer
+    int hand_over_range(hipEvent_t ev, int64_t lo, int64_t hi)
+    {
+        const int64_t piece = std::max<int64_t>(1, (int64_t)(F->lane_bytes / (sizeof(double) * (size_t)F->E)));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int64_t a = lo; a < hi; a += piece) q.push_back({ev, a, std::min(hi, a + piece)});
+        }
+        cv.notify_all();
+        return MI355_OK;
+    }
     int hand_over(size_t k, hipStream_t st)
     {
         while (F->copy_ev.size() <= k) {
@@ -321,25 +342,36 @@ struct HostCopier {
             F->copy_ev.push_back(e);
         }
         HIP_TRY(hipEventRecord(F->copy_ev[k], st));
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            q.push_back({F->copy_ev[k], F->copy_plan[k].lo, F->copy_plan[k].hi});
-        }
-        cv.notify_one();
-        return MI355_OK;
+        return hand_over_range(F->copy_ev[k], F->copy_plan[k].lo, F->copy_plan[k].hi);
     }
-    // wait for every copy handed over so far; the thread ends
+    // wait for every copy handed over so far; the threads end
     int finish()
     {
-        if (th.joinable()) {
-            { std::lock_guard<std::mutex> lk(mu); closed = true; }
-            cv.notify_one();
-            th.join();
-        }
+        { std::lock_guard<std::mutex> lk(mu); closed = true; }
+        cv.notify_all();
+        for (std::thread &t : th) if (t.joinable()) t.join();
+        th.clear();
         if (err != hipSuccess) return fail(MI355_GPU_PROBLEM, std::string("copy of the factor to the host failed: ") + hipGetErrorString(err));
         return MI355_OK;
     }
 };
+
+// the lanes of the handle (tuning key 20 = how many, key 21 = MB per staging buffer), made on first use
+int make_lanes(mi355_factor_s *F)
+{
+    if (!F->lane_stream.empty()) return MI355_OK;
+    const int lanes = std::max(1, std::min(32, tuning().host_lanes));
+    F->lane_bytes = (size_t)std::max(1, tuning().host_lane_mb) << 20;
+    for (int l = 0; l < lanes; l++) {
+        void *p = nullptr;
+        HIP_TRY(hipHostMalloc(&p, F->lane_bytes, hipHostMallocDefault));
+        F->lane_pin.push_back(p);
+        hipStream_t st = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        F->lane_stream.push_back(st);
+    }
+    return MI355_OK;
+}
 
 // run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
 int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double beta, EventTimer &tm,
@@ -613,6 +645,8 @@ int mi355_factor_free(mi355_factor *F)
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
     for (hipEvent_t ev : F->side_ev) (void)hipEventDestroy(ev);
     if (F->copy_stream) { (void)hipStreamSynchronize(F->copy_stream); (void)hipStreamDestroy(F->copy_stream); }
+    for (hipStream_t st : F->lane_stream) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (void *p : F->lane_pin) (void)hipHostFree(p);
     for (hipEvent_t ev : F->copy_ev) (void)hipEventDestroy(ev);
     if (F->ev0) (void)hipEventDestroy(F->ev0);
     if (F->ev1) (void)hipEventDestroy(F->ev1);
@@ -735,6 +769,27 @@ int mi355_factor_set_matrix_zomplex(mi355_factor *F, const int64_t *Ap, const in
 
 namespace {
 
+// all of Lx to the host through the lanes (everything enqueued on the compute stream so far is waited for)
+int copy_all_to_host(mi355_factor_s *F, double *host_Lx)
+{
+    int rc = make_lanes(F);
+    if (rc) return rc;
+    if (F->copy_ev.empty()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        F->copy_ev.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(F->copy_ev[0], F->stream));
+    try {
+        HostCopier hc(F, host_Lx);
+        rc = hc.hand_over_range(F->copy_ev[0], 0, F->sym.xsize);
+        const int rc2 = hc.finish();
+        return rc ? rc : rc2;
+    } catch (const std::exception &e) {
+        return fail(MI355_OUT_OF_MEMORY, std::string("cannot start the copy threads: ") + e.what());
+    }
+}
+
 // the numeric factorization; host_Lx != NULL: L->x on the host is filled as well, chunk by chunk while the
 // factorization runs (mi355_factor_numeric_host)
 int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef, int64_t *minor, int *status,
@@ -748,7 +803,8 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
     F->st_copy_early = 0;
     std::unique_ptr<HostCopier> hc;
     if (host_Lx && S.xsize > 0 && S.nsuper > 0) {
-        if (!F->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&F->copy_stream, hipStreamNonBlocking));
+        rc = make_lanes(F);
+        if (rc) return rc;
         if (F->copy_plan.empty()) {
             // chunks of 32 M entries (256 MB real): large enough for PCIe to run at its rate, small enough that the
             // bottom of the tree leaves while the top is still being factorized
@@ -819,8 +875,8 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
         if (sf != big) {
             // the rare failing case: what left early is not what the replay produced -- one plain copy of everything
             F->st_copy_early = 0;
-            HIP_TRY(hipMemcpyAsync(host_Lx, F->Lx.p, (size_t)S.xsize * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
-            HIP_TRY(hipStreamSynchronize(F->stream));
+            rc = copy_all_to_host(F, host_Lx);
+            if (rc) return rc;
         }
     }
     HIP_TRY(hipEventRecord(e1, F->stream));
@@ -897,10 +953,7 @@ int mi355_factor_get_Lx(mi355_factor *F, double *Lx)
     int rc = check_handle(F);
     if (rc) return rc;
     if (!Lx) return fail(MI355_INVALID, "null Lx");
-    if (F->sym.xsize > 0) {
-        HIP_TRY(hipMemcpyAsync(Lx, F->Lx.p, (size_t)F->sym.xsize * F->E * sizeof(double), hipMemcpyDeviceToHost, F->stream));
-        HIP_TRY(hipStreamSynchronize(F->stream));
-    }
+    if (F->sym.xsize > 0) return copy_all_to_host(F, Lx);
     return MI355_OK;
 }
 
@@ -1839,6 +1892,8 @@ int mi355_set_tuning(int key, int value)
     else if (key == 17) tuning().dist_pieces = value ? 1 : 0;
     else if (key == 18) tuning().host_chunk = std::max(1, value);
     else if (key == 19) tuning().dist_reduce_channel = value ? 1 : 0;
+    else if (key == 20) tuning().host_lanes = std::max(1, value);
+    else if (key == 21) tuning().host_lane_mb = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -402,12 +402,13 @@ class SupernodalFactor:
         self.minor, self.status = int(minor.value), int(status.value)
         return self.status
 
-    def numeric_host(self, beta=0.0, quick_return_if_not_posdef=False):
+    def numeric_host(self, beta=0.0, quick_return_if_not_posdef=False, out=None):
         """mi355_factor_numeric_host: factorize and fill a host L->x while the factorization runs; returns
-        (status, Lx)"""
+        (status, Lx); out: a float64 array of at least E * xsize entries to fill instead of a new one"""
         minor = C.c_int64(0)
         status = C.c_int(0)
-        out = np.full(max(self.xsize, 1) * self.E, np.nan)
+        if out is None:
+            out = np.full(max(self.xsize, 1) * self.E, np.nan)
         f = lib().mi355_factor_numeric_host
         f.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
         _check(f(self._h, float(beta), int(bool(quick_return_if_not_posdef)), out.ctypes.data_as(C.c_void_p),
@@ -440,8 +441,10 @@ class SupernodalFactor:
         self.set_matrix(Sp, Si, Sx, Snz, Sz)
         return self.numeric(b, quick_return_if_not_posdef)
 
-    def Lx(self):
-        out = np.zeros(max(self.xsize, 1) * self.E)
+    def Lx(self, out=None):
+        """L->x on the host; out: a float64 array of at least E * xsize entries to fill instead of a new one"""
+        if out is None:
+            out = np.zeros(max(self.xsize, 1) * self.E)
         _check(lib().mi355_factor_get_Lx(self._h, out))
         out = out[:self.xsize * self.E]
         return out.view(np.complex128) if self.E == 2 else out

@@ -512,6 +512,9 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
     return hipSuccess;
 }
 inline hipError_t hipGetSymbolAddress(void **p, const void *symbol) { *p = const_cast<void *>(symbol); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void *p) { (void)hipDeviceSynchronize(); std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
