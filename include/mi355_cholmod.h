@@ -402,7 +402,8 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * stream of its own for the sums of the top's ranges into their owners, awaited supernode by supernode where the top
  * first touches them instead of all before the top; default 0 until it has been measured on xGMI); keys 20 / 21: lanes of the
  * copy of the factor to the host (threads, each with a pinned staging buffer and a stream; default 8) and MB per
- * staging buffer (default 32), read when a handle copies for the first time; keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * staging buffer (default 32), read when a handle copies for the first time; key 22: smallest B (KB) that mi355_solve /
+ * mi355_solve_x move through the lanes (default 4096; smaller ones take one plain copy); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

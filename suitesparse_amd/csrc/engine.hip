@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -154,6 +155,8 @@ struct mi355_factor_s {
     std::vector<void *> lane_pin;
     std::vector<hipStream_t> lane_stream;
     size_t lane_bytes = 0;
+    DevBuf<double> solve_b, solve_x;            // device images of B and X of mi355_solve_x, kept from call to call
+    size_t solve_b_cap = 0, solve_x_cap = 0;
     double st_copy_early = 0;                   // entries copied before the last step had been enqueued
     double st_red_overlap = 0;                  // reduce channel: launches of the top enqueued before the last reduction was awaited
 };
@@ -371,6 +374,61 @@ int make_lanes(mi355_factor_s *F)
         F->lane_stream.push_back(st);
     }
     return MI355_OK;
+}
+
+// Host <-> device through the lanes: pieces (each at most one staging buffer) are taken by the lanes' threads in turn.
+// To the device: memcpy into the lane's pinned buffer, DMA, wait -- the data is on the device when the call returns.
+// To the host: every lane first waits for `after` (recorded on the stream that produces the data), then DMA into the
+// pinned buffer and memcpy out.  Pageable memory on the host side at PCIe rate either way.
+struct LanePiece { char *host; char *dev; size_t bytes; };
+int lanes_transfer(mi355_factor_s *F, const std::vector<LanePiece> &pieces, bool to_device, hipEvent_t after)
+{
+    int rc = make_lanes(F);
+    if (rc) return rc;
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    hipError_t err = hipSuccess;
+    auto work = [&](size_t lane) {
+        hipError_t e = hipSetDevice(F->device);
+        if (e == hipSuccess && after) e = hipEventSynchronize(after);
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= pieces.size() || e != hipSuccess) break;
+            const LanePiece &p = pieces[k];
+            if (to_device) {
+                memcpy(F->lane_pin[lane], p.host, p.bytes);
+                e = hipMemcpyAsync(p.dev, F->lane_pin[lane], p.bytes, hipMemcpyHostToDevice, F->lane_stream[lane]);
+                if (e == hipSuccess) e = hipStreamSynchronize(F->lane_stream[lane]);
+            } else {
+                e = hipMemcpyAsync(F->lane_pin[lane], p.dev, p.bytes, hipMemcpyDeviceToHost, F->lane_stream[lane]);
+                if (e == hipSuccess) e = hipStreamSynchronize(F->lane_stream[lane]);
+                if (e == hipSuccess) memcpy(p.host, F->lane_pin[lane], p.bytes);
+            }
+        }
+        if (e != hipSuccess) { std::lock_guard<std::mutex> lk(mu); err = e; }
+    };
+    const size_t nl = std::min(F->lane_stream.size(), pieces.size());
+    try {
+        std::vector<std::thread> th;
+        for (size_t l = 1; l < nl; l++) th.emplace_back(work, l);
+        work(0);                                   // the calling thread is lane 0
+        for (std::thread &t : th) t.join();
+    } catch (const std::exception &e) {
+        return fail(MI355_OUT_OF_MEMORY, std::string("cannot start the copy threads: ") + e.what());
+    }
+    if (err != hipSuccess) return fail(MI355_GPU_PROBLEM, std::string("staged copy failed: ") + hipGetErrorString(err));
+    return MI355_OK;
+}
+
+// the pieces of a matrix of `cols` columns of `width` bytes (host pitch hp, device pitch dp)
+void lane_pieces(mi355_factor_s *F, char *host, size_t hp, char *dev, size_t dp, size_t width, size_t cols,
+                 std::vector<LanePiece> &out)
+{
+    const size_t cap = F->lane_bytes;
+    if (hp == width && dp == width) { width *= cols; cols = 1; }       // contiguous on both sides: one long run
+    for (size_t j = 0; j < cols; j++)
+        for (size_t a = 0; a < width; a += cap)
+            out.push_back({host + j * hp + a, dev + j * dp + a, std::min(cap, width - a)});
 }
 
 // run one schedule: zero Lx, assemble the first ncols_asm columns of A, then the steps
@@ -1816,13 +1874,33 @@ int mi355_solve_x(mi355_factor *F, int sys, int64_t nrhs, int bxtype, const doub
     if (!B || !X) return fail(MI355_INVALID, "null argument");
     const int Eb = (bxtype == MI355_COMPLEX) ? 2 : 1, Ex = (Eb == 2 || F->E == 2) ? 2 : 1;
     const size_t bs = (size_t)Eb * sizeof(double), xs = (size_t)Ex * sizeof(double);
-    DevBuf<double> dB, dX;
-    HIP_TRY(dB.alloc((size_t)n * nrhs * Eb));
-    HIP_TRY(dX.alloc((size_t)n * nrhs * Ex));
-    HIP_TRY(hipMemcpy2DAsync(dB.p, n * bs, B, ldb * bs, n * bs, (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
-    rc = mi355_solve_x_dev(F, sys, nrhs, bxtype, dB.p, n, dX.p, n);
+    // device images of B and X, kept by the handle from call to call (cholmod_solve2's Y / E workspaces play that part
+    // in the reference, cholmod_solve.c:119-153)
+    const size_t need_b = (size_t)n * nrhs * Eb, need_x = (size_t)n * nrhs * Ex;
+    if (F->solve_b_cap < need_b) { HIP_TRY(F->solve_b.alloc(need_b)); F->solve_b_cap = need_b; }
+    if (F->solve_x_cap < need_x) { HIP_TRY(F->solve_x.alloc(need_x)); F->solve_x_cap = need_x; }
+    double *dB = F->solve_b.p, *dX = F->solve_x.p;
+    const bool staged = need_b * sizeof(double) >= ((size_t)std::max(0, tuning().host_staged_min_kb) << 10);   // small ones: not worth the threads
+    if (staged) {
+        // B and X are pageable host memory: through the lanes (pinned staging, parallel memcpy) at PCIe rate
+        rc = make_lanes(F);                         // (sets the staging size the pieces are cut to)
+        if (rc) return rc;
+        std::vector<LanePiece> pieces;
+        lane_pieces(F, (char *)const_cast<double *>(B), ldb * bs, (char *)dB, n * bs, n * bs, (size_t)nrhs, pieces);
+        rc = lanes_transfer(F, pieces, true, nullptr);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(dB, n * bs, B, ldb * bs, n * bs, (size_t)nrhs, hipMemcpyHostToDevice, F->stream));
+    }
+    rc = mi355_solve_x_dev(F, sys, nrhs, bxtype, dB, n, dX, n);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(X, ldx * xs, dX.p, n * xs, n * xs, (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
+    if (staged) {
+        HIP_TRY(hipEventRecord(F->ev1, F->stream));
+        std::vector<LanePiece> pieces;
+        lane_pieces(F, (char *)X, ldx * xs, (char *)dX, n * xs, n * xs, (size_t)nrhs, pieces);
+        return lanes_transfer(F, pieces, false, F->ev1);
+    }
+    HIP_TRY(hipMemcpy2DAsync(X, ldx * xs, dX, n * xs, n * xs, (size_t)nrhs, hipMemcpyDeviceToHost, F->stream));
     HIP_TRY(hipStreamSynchronize(F->stream));
     return MI355_OK;
 }
@@ -1894,6 +1972,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 19) tuning().dist_reduce_channel = value ? 1 : 0;
     else if (key == 20) tuning().host_lanes = std::max(1, value);
     else if (key == 21) tuning().host_lane_mb = std::max(1, value);
+    else if (key == 22) tuning().host_staged_min_kb = std::max(0, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

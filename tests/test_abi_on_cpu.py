@@ -420,3 +420,34 @@ def test_blas_timer_statistics(engine):
 def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
     import test_gpu_parity as tp
     tp.test_numeric_host_copies_under_the_factorization(engine, name, chunk)
+
+
+def test_host_solve_through_the_lanes(engine):
+    """mi355_solve_x with host B / X moved through the lanes (tuning key 22 = 0: every size; key 21 = 1 MB staging buffers
+    so that a column is cut into pieces): real and complex right-hand sides, twice (the device
+    images of B and X are kept from call to call), against the plain path"""
+    g = load_golden("lap3d_8_metis")
+    n = g["n"]
+    rng = np.random.default_rng(2)
+    L = engine.SupernodalFactor(sym_of(g))
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    assert L.numeric(beta=g["beta"]) == 0
+    L.set_perm(g["Perm"])
+    want = {}
+    for cplx in (False, True):
+        B = rng.standard_normal((n, 5)) + (1j * rng.standard_normal((n, 5)) if cplx else 0)
+        want[cplx] = (B, L.solve(B, sys=0))
+    L.close()
+    engine.set_tuning(22, 0); engine.set_tuning(21, 1); engine.set_tuning(20, 3)
+    try:
+        L = engine.SupernodalFactor(sym_of(g))
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        assert L.numeric(beta=g["beta"]) == 0
+        L.set_perm(g["Perm"])
+        for _ in range(2):
+            for cplx in (False, True):
+                B, X = want[cplx]
+                assert relerr(L.solve(B, sys=0), X) < 1e-13
+        L.close()
+    finally:
+        engine.set_tuning(22, 4096); engine.set_tuning(21, 32); engine.set_tuning(20, 8)
