@@ -520,3 +520,48 @@ def test_fuzz_public_api_against_the_unchanged_build(which, seed):
         A = _dense_A(g)
         assert _demo_resid(A, r.solve2("A", B), B) < 1e-12
     r.close(); u.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_full_size_dropin_factorize_and_solve():
+    """cholmod_l_analyze -> cholmod_l_factorize -> cholmod_l_solve through the patched CHOLMOD on the real library at a
+    size where time matters (3D 7-point 64^3, lower-stored A, the engine's nested-dissection permutation given to
+    analyze), beside the unchanged build on the host cores: the same factor to 1e-10, the demo's residual criterion,
+    and the wall-clock times of the PUBLIC calls -- what a CHOLMOD user sees, host copies of L->x and of the right-hand
+    sides included -- written to gpurun_out/r02/dropin_timing.json (the first factorize call also creates the handle)."""
+    import json
+    import time
+    from suitesparse_amd import problems, symbolic
+    p = problems.laplacian_3d(64)
+    perm = symbolic.nd_grid_order(p["shape"], p["dof"])
+    n = p["n"]
+    g = dict(n=n, Ap=p["Ap"], Ai=p["Ai"], Ax=p["Ax"], stype=-1)
+    r, u = _both_builds("gpu", g)
+    t = {}
+    for name, x in (("dropin", r), ("reference_cpu", u)):
+        t0 = time.perf_counter(); inf = x.analyze(perm=perm, supernodal=2); t[name + "_analyze_s"] = time.perf_counter() - t0
+        assert inf["is_super"] == 1
+        for k in ("first", "second"):
+            t0 = time.perf_counter(); st = x.factorize_full(); t[f"{name}_factorize_{k}_s"] = time.perf_counter() - t0
+            assert st == 0
+    assert r.calls_taken()[3] >= 2                      # the unpermuted A went to the device both times
+    fl = float(r.info().get("fl", 0.0)) or None
+    Lr, Lu = r.Lx(), u.Lx()
+    assert relerr(Lr, Lu) < 1e-10
+    rng = np.random.default_rng(0)
+    for nrhs in (1, 16):
+        B = rng.standard_normal((n, nrhs))
+        for name, x in (("dropin", r), ("reference_cpu", u)):
+            x.solve2("A", B)                            # warm-up (workspaces, device images)
+            t0 = time.perf_counter(); X = x.solve2("A", B); t[f"{name}_solve_nrhs{nrhs}_s"] = time.perf_counter() - t0
+            if name == "dropin":
+                Xr = X
+        assert relerr(Xr, X) < 1e-9
+    t.update(problem="lap3d 64", n=n, xsize=int(r.symbolic()["Lpx"][-1]), fl=fl, threads_reference=u.nthreads())
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r02"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r02", "dropin_timing.json"), "w") as fh:
+        json.dump(t, fh, indent=1)
+    print(json.dumps(t))
+    assert t["dropin_factorize_second_s"] < t["reference_cpu_factorize_second_s"]
+    r.close(); u.close()
