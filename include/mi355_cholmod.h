@@ -401,7 +401,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * N-rank driver (read by mi355_comm_create_rccl / _adopt_rccl: a second communicator made with ncclCommSplit and a
  * stream of its own for the sums of the top's ranges into their owners, awaited supernode by supernode where the top
  * first touches them instead of all before the top; default 0 until it has been measured on xGMI); keys 20 / 21: lanes of the
- * copy of the factor to the host (threads, each with a pinned staging buffer and a stream; default 8) and MB per
+ * copy of the factor to the host (threads, each with a pinned staging buffer and a stream; default 4: they saturate PCIe Gen5 on the MI355X box) and MB per
  * staging buffer (default 32), read when a handle copies for the first time; key 22: smallest B (KB) that mi355_solve /
  * mi355_solve_x move through the lanes (default 4096; smaller ones take one plain copy); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);

@@ -450,4 +450,4 @@ def test_host_solve_through_the_lanes(engine):
                 assert relerr(L.solve(B, sys=0), X) < 1e-13
         L.close()
     finally:
-        engine.set_tuning(22, 4096); engine.set_tuning(21, 32); engine.set_tuning(20, 8)
+        engine.set_tuning(22, 4096); engine.set_tuning(21, 32); engine.set_tuning(20, 4)

@@ -51,7 +51,7 @@ def main():
                resident_s=t_res, numeric_then_get_Lx_s=t_ser, numeric_host_s=t_host,
                gflops_resident=sym["fl"] / t_res * 1e-9, gflops_host_inclusive=sym["fl"] / t_host * 1e-9,
                chunks=int(len(L.host_copy_plan())), early_fraction=early / max(sym["xsize"], 1),
-               lanes=int(sys.argv[3]) if len(sys.argv) > 3 else 8, lane_mb=int(sys.argv[4]) if len(sys.argv) > 4 else 32)
+               lanes=int(sys.argv[3]) if len(sys.argv) > 3 else 4, lane_mb=int(sys.argv[4]) if len(sys.argv) > 4 else 32)
     print(json.dumps(res))
     if out:
         with open(out, "w") as f:
