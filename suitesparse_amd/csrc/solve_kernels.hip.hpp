@@ -450,6 +450,10 @@ __global__ __launch_bounds__(256) void k_solve_group(
 // and handles up to 64 right-hand sides [j0, j0+64) per launch; the right-hand sides run along lane%16 of
 // the MFMA result, so stores and atomics touch runs of 16 consecutive doubles.
 //------------------------------------------------------------------------------
+// occupancy target of a kernel (waves per SIMD): the register allocator may use 512 / n VGPRs
+#ifndef MI355_WAVES_PER_EU          // (the CPU stand-in of the HIP header, tests only, defines it away)
+#define MI355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 constexpr int SM_LD = 66;            // LDS row stride in doubles: 16 rows x 4 k land on disjoint banks
 
 // Complex L (E = 2): Y is still handled as a REAL row-major matrix -- the interleaved (re, im) pairs of the
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_mma(
 // at the top of the next pass.  Complex: Im(L) stays in registers and the second product reads the
 // pair-swapped image of Y from the same LDS rows.  One set of atomics per run.
 template <int E>
-__global__ __launch_bounds__(256) void k_solve_bwd_mma_run(
+__global__ __launch_bounds__(256) MI355_WAVES_PER_EU(E == 1 ? 3 : 2) void k_solve_bwd_mma_run(
     const PotrfTask *__restrict__ tasks, const SolveRange *__restrict__ work,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrhs, int j0)

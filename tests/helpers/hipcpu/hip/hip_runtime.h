@@ -294,6 +294,7 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define MI355_WAVES_PER_EU(n)
 #define __align__(n) __attribute__((aligned(n)))
 #define HIP_SYMBOL(x) ((const void *)&(x))
 #define __shared__ static
