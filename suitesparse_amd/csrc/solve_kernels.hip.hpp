@@ -15,6 +15,10 @@
 #pragma once
 #include "kernels.hip.hpp"
 
+// occupancy target of a kernel (waves per SIMD): the register allocator may use 512 / n VGPRs
+#ifndef MI355_WAVES_PER_EU          // (the CPU stand-in of the HIP header, tests only, defines it away)
+#define MI355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 namespace mi355 {
 
 constexpr int SOLVE_NR = 4;      // right-hand sides per register pass
@@ -450,10 +454,6 @@ __global__ __launch_bounds__(256) void k_solve_group(
 // and handles up to 64 right-hand sides [j0, j0+64) per launch; the right-hand sides run along lane%16 of
 // the MFMA result, so stores and atomics touch runs of 16 consecutive doubles.
 //------------------------------------------------------------------------------
-// occupancy target of a kernel (waves per SIMD): the register allocator may use 512 / n VGPRs
-#ifndef MI355_WAVES_PER_EU          // (the CPU stand-in of the HIP header, tests only, defines it away)
-#define MI355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
 constexpr int SM_LD = 66;            // LDS row stride in doubles: 16 rows x 4 k land on disjoint banks
 
 // Complex L (E = 2): Y is still handled as a REAL row-major matrix -- the interleaved (re, im) pairs of the
