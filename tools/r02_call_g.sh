@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 2, GPU call G: evidence of the final tree after the solve-kernel occupancy commits: the driver's own test
+# command, smoke, the driver's bench command, the multi-RHS solve line, then the round profile.  Steps chained:
+# nothing follows a failure.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02g; mkdir -p $O
+cd $R
+timeout -k 10 600 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > $O/gpu_tests.log 2>&1 \
+  || { tail -30 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log
+timeout -k 10 120 python -u -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail $O/smoke.log; exit 1; }
+tail -2 $O/smoke.log
+timeout -k 10 400 python -u bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_lap3d150.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
+cat $O/bench_lap3d150.json
+timeout -k 10 200 python -u bench.py --problem lap3d --steps 2 --warmup 1 --no-cpu --solve --nrhs 64 > $O/bench_solve64.json 2> $O/solve64.err || { tail $O/solve64.err; exit 1; }
+cat $O/bench_solve64.json
+timeout -k 10 200 python -u bench.py --problem helm --steps 2 --warmup 1 --no-cpu --solve --nrhs 64 > $O/bench_helm_solve64.json 2> $O/helm64.err || { tail $O/helm64.err; exit 1; }
+cat $O/bench_helm_solve64.json
+bash tools/profile_round.sh r02g
