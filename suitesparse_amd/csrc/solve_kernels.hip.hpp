@@ -513,6 +513,29 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
     const int64_t e0 = (int64_t)blockIdx.x * group, e1 = min(e0 + (int64_t)group, ntiles);
     int cur = -1;
     PotrfTask t = tasks[tile_task[e0]];
+    double al[16], ai[E == 2 ? 16 : 1];
+    // the operand of tile e of block tt: this lane's row, 16 k-steps of 4 columns
+    auto load_tile = [&](const PotrfTask &tt, int64_t e) {
+        const int nq = (tt.nb + 3) >> 2;                 // k-steps of 4 columns that hold anything
+        const int r = tt.urow0 + (int)(e - tt.stile0) * SOLVE_ROWS + w * 16 + l15;
+        const int64_t roff = tt.a_off + ((r < tt.lda ? r : tt.col0) - tt.col0);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = 4 * q + l4;
+            const int64_t off = roff + (int64_t)(c < tt.nb ? c : 0) * tt.lda;   // c >= nb: finite value against a zero of Xs
+            if constexpr (E == 2) {
+                const double2 v = (q < nq) ? reinterpret_cast<const double2 *>(Lx)[off] : make_double2(0.0, 0.0);
+                al[q] = v.x; ai[q] = v.y;
+            } else {
+                al[q] = (q < nq) ? Lx[off] : 0.0;
+            }
+        }
+    };
+    // complex blocks (twice the bytes and twice the products per tile) request the next tile's operand before the
+    // results of the current one go out: 42.1 -> 39.5 ms at helm 100^3, nrhs = 64; real blocks measured 3 % slower
+    // that way (53.6 -> 55.2 ms at 150^3) and load where they use
+    constexpr bool AHEAD = (E == 2);
+    if constexpr (AHEAD) load_tile(t, e0);
     for (int64_t e = e0; e < e1; e++) {
         const int ti = tile_task[e];
         if (ti != cur) {
@@ -529,23 +552,9 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
             }
             __syncthreads();
         }
-        const int nb = t.nb;
-        const int nq = (nb + 3) >> 2;                    // k-steps of 4 columns that hold anything
+        const int nq = (t.nb + 3) >> 2;
         const int rbase = t.urow0 + (int)(e - t.stile0) * SOLVE_ROWS + w * 16;       // first row of this wave
-        const int r = rbase + l15;                       // operand row of this lane
-        const int64_t roff = t.a_off + ((r < t.lda ? r : t.col0) - t.col0);
-        double al[16], ai[E == 2 ? 16 : 1];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int c = 4 * q + l4;
-            const int64_t off = roff + (int64_t)(c < nb ? c : 0) * t.lda;   // c >= nb: finite value against a zero of Xs
-            if constexpr (E == 2) {
-                const double2 v = (q < nq) ? reinterpret_cast<const double2 *>(Lx)[off] : make_double2(0.0, 0.0);
-                al[q] = v.x; ai[q] = v.y;
-            } else {
-                al[q] = (q < nq) ? Lx[off] : 0.0;
-            }
-        }
+        if constexpr (!AHEAD) load_tile(t, e);
         v4d acc[4];
 #pragma unroll
         for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -559,6 +568,9 @@ __global__ __launch_bounds__(256) void k_solve_fwd_mma(
                 if constexpr (E == 2)
                     acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], Xs2[16 * jb + l15][4 * q + l4], acc[jb], 0, 0, 0);
             }
+        }
+        if constexpr (AHEAD) {
+            if (e + 1 < e1) load_tile(tasks[tile_task[e + 1]], e + 1);       // its latency runs under the atomics
         }
         // result: rows rbase + lane/16 + 4g (g = 0..3), right-hand side 16 jb + lane%16
 #pragma unroll
