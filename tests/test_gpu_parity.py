@@ -286,7 +286,10 @@ def test_multigpu_phases_simulated_on_one_gpu(engine, world):
 
 
 @pytest.mark.parametrize("world,ob,ob2,size,kind", [(2, 64, 128, 16, "lap3d"), (4, 64, 64, 16, "lap3d"),
-                                                     (3, 256, 1024, 24, "lap3d"), (3, 64, 128, 12, "helm")])
+                                                     (3, 256, 1024, 24, "lap3d"), (3, 64, 128, 12, "helm"),
+                                                     # default block widths, top supernodes of several 1024-column blocks
+                                                     # (root 2531 / 1048 columns): the shape of the first 8-GPU run
+                                                     (4, 256, 1024, 40, "lap3d"), (2, 256, 1024, 26, "helm")])
 def test_distributed_top_simulated_on_one_gpu(engine, world, ob, ob2, size, kind):
     """owner-computes top (mi355_factor_set_top_distribution / _top_plan / _top_run) with `world` handles on
     one GPU; the broadcasts and the sums are done by hand on the device views RCCL would use"""
