@@ -67,6 +67,15 @@ int cholmod_mi355_live_handles (void) ;
  * device (tests: the device path, not a silent CPU one, produced a result) */
 void cholmod_mi355_calls_taken (int64_t out [4]) ;
 
+/* Soft fallback (the reference never fails a factorization because of its GPU: gpu_init failing turns the GPU off for the
+ * call, CHOLMOD/Supernodal/t_cholmod_super_numeric_worker.c:233-244, CHOLMOD/GPU/t_cholmod_gpu.c:107-118): when the device
+ * cannot take a factorization -- the factor does not fit the memory the device has free or Common->maxGpuMemBytes /
+ * maxGpuMemFraction allow (environment CHOLMOD_GPU_MEM_BYTES / _FRACTION read with CHOLMOD_USE_GPU, as
+ * CHOLMOD/Supernodal/cholmod_super_symbolic.c:250-289 does), an allocation fails, the device run fails -- L->useGPU is
+ * set to 0 and the unchanged CPU worker factorizes, silently as in the reference.  Returns how often that has happened
+ * since the library was loaded; reason (may be NULL): the engine's message of the last time. */
+int64_t cholmod_mi355_fallbacks (char *reason, size_t len) ;
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,28 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper,
                         const int64_t *Ls, int64_t ssize, int64_t xsize,
                         int device, mi355_factor **handle);
 
+/* mi355_factor_create with a cap on the device memory the handle may take.  Replaces the sizing of the reference's device
+ * pool from Common->maxGpuMemBytes / Common->maxGpuMemFraction (CHOLMOD/GPU/cholmod_gpu.c:446-489; environment
+ * CHOLMOD_GPU_MEM_BYTES / CHOLMOD_GPU_MEM_FRACTION, CHOLMOD/Supernodal/cholmod_super_symbolic.c:266-279): max_bytes > 0
+ * and / or 0 < max_fraction <= 1 of the device's total memory, the smaller one counts; both 0: whatever is free less the
+ * 50 MB the reference leaves to the driver (cholmod_gpu.c:464-471).  What the handle needs -- the factor, the block
+ * inverses, the symbolic arrays and the schedule's tables -- is computed from the schedule BEFORE anything is allocated:
+ * if it exceeds the cap nothing is allocated and MI355_OUT_OF_MEMORY is returned (a caller with a CPU path, such as
+ * CHOLMOD, then takes it: the soft fallback of t_cholmod_super_numeric_worker.c:236-237).  *needed_bytes (may be NULL)
+ * receives the figure either way. */
+int mi355_factor_create_limited(int xtype, int64_t n, int64_t nsuper, const int64_t *Super,
+                                const int64_t *Lpi, const int64_t *Lpx, const int64_t *Ls,
+                                int64_t ssize, int64_t xsize, int device, int64_t max_bytes, double max_fraction,
+                                int64_t *needed_bytes, mi355_factor **handle);
+
+/* Total and free memory of a device in bytes (cholmod_l_gpu_memorysize, CHOLMOD/GPU/cholmod_gpu.c:63-131, without its
+ * trial allocations). */
+int mi355_device_memory(int device, int64_t *total_bytes, int64_t *free_bytes);
+
+/* The calling thread's current HIP device: the reference works on the current device (cudaGetDevice,
+ * CHOLMOD/GPU/cholmod_gpu.c:165), so the CHOLMOD glue passes this to mi355_factor_create. */
+int mi355_current_device(int *device);
+
 /* replaces cholmod_l_gpu_deallocate / gpu_end (cholmod_gpu.c:187,319) */
 int mi355_factor_free(mi355_factor *handle);
 
@@ -403,7 +425,10 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * first touches them instead of all before the top; default 0 until it has been measured on xGMI); keys 20 / 21: lanes of the
  * copy of the factor to the host (threads, each with a pinned staging buffer and a stream; default 4: they saturate PCIe Gen5 on the MI355X box) and MB per
  * staging buffer (default 32), read when a handle copies for the first time; key 22: smallest B (KB) that mi355_solve /
- * mi355_solve_x move through the lanes (default 4096; smaller ones take one plain copy); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * mi355_solve_x move through the lanes (default 4096; smaller ones take one plain copy); key 23: the wide multi-RHS
+ * sweeps (default 1: the rows below a solve group of more than 64 columns take all its columns in one pass -- contraction
+ * depth 256, 128 for a complex factor -- instead of one pass per 64-column block; 0: per-block kernels everywhere); key 24:
+ * workgroups aimed at per launch of the wide kernels (default 256 = one per CU; read when a handle builds its solve lists); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

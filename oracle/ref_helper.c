@@ -422,6 +422,17 @@ int ref_solve (void *hv, int64_t nrhs, const double *Bx, double *Xx)
 // ---- drop-in build only (oracle/build_ref_mi355.sh: the same helper linked to libcholmod_mi355.so) --------------------
 // Common->useGPU before the next analyze: 1 request the device, 0 CPU workers, -1 ask the environment (CHOLMOD_USE_GPU)
 void ref_set_use_gpu (void *hv, int use) { ((ref_ctx *) hv)->cm.useGPU = use ; }
+// Common->maxGpuMemBytes / maxGpuMemFraction (cholmod.h; read by cholmod_l_gpu_allocate in the reference)
+void ref_set_gpu_mem (void *hv, double bytes, double fraction)
+{
+    ((ref_ctx *) hv)->cm.maxGpuMemBytes = (size_t) bytes ;
+    ((ref_ctx *) hv)->cm.maxGpuMemFraction = fraction ;
+}
+void ref_get_gpu_mem (void *hv, double *out)
+{
+    out [0] = (double) ((ref_ctx *) hv)->cm.maxGpuMemBytes ;
+    out [1] = ((ref_ctx *) hv)->cm.maxGpuMemFraction ;
+}
 
 // out[10]: Common->useGPU, L->useGPU, then the BLAS statistics of cholmod.h:966-986:
 // gpu gemm calls, gpu potrf calls, gpu gemm time, gpu potrf time, assemble time,
@@ -466,7 +477,10 @@ int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
 void ref_calls_taken (int64_t *out) { cholmod_mi355_calls_taken (out) ; }
 void cholmod_mi355_forget (cholmod_factor *L) ;
 void ref_forget (void *hv) { cholmod_mi355_forget (((ref_ctx *) hv)->L) ; }
+int64_t cholmod_mi355_fallbacks (char *reason, size_t len) ;
+int64_t ref_fallbacks (char *reason, int64_t len) { return cholmod_mi355_fallbacks (reason, (size_t) len) ; }
 #else
+int64_t ref_fallbacks (char *reason, int64_t len) { if (reason && len > 0) reason [0] = 0 ; return -1 ; }
 void ref_forget (void *hv) { (void) hv ; }
 int ref_live_handles (void) { return -1 ; }
 void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = out [3] = -1 ; }

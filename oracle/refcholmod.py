@@ -86,6 +86,10 @@ def _prototypes(L):
     L.ref_super_solve.argtypes = [C.c_void_p, C.c_int, C.c_int64, f64p, C.c_int64]
     L.ref_solve.argtypes = [C.c_void_p, C.c_int64, f64p, f64p]
     L.ref_set_use_gpu.argtypes = [C.c_void_p, C.c_int]
+    L.ref_set_gpu_mem.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.ref_get_gpu_mem.argtypes = [C.c_void_p, f64p]
+    L.ref_fallbacks.argtypes = [C.c_char_p, C.c_int64]
+    L.ref_fallbacks.restype = C.c_int64
     L.ref_counters.argtypes = [C.c_void_p, f64p]
     L.ref_drop_factor.argtypes = [C.c_void_p]
     L.ref_make_simplicial.argtypes = [C.c_void_p, C.c_int]
@@ -124,6 +128,21 @@ class RefCholmod:
     # ---- drop-in build ----
     def set_use_gpu(self, use):
         self.L.ref_set_use_gpu(self.h, int(use))
+
+    def set_gpu_mem(self, max_bytes=0, max_fraction=0.0):
+        """Common->maxGpuMemBytes / maxGpuMemFraction"""
+        self.L.ref_set_gpu_mem(self.h, float(max_bytes), float(max_fraction))
+
+    def gpu_mem(self):
+        out = np.zeros(2)
+        self.L.ref_get_gpu_mem(self.h, out)
+        return float(out[0]), float(out[1])
+
+    def fallbacks(self):
+        """(count, reason of the last one) of the drop-in's soft fallbacks to the CPU worker"""
+        buf = C.create_string_buffer(512)
+        k = int(self.L.ref_fallbacks(buf, 512))
+        return k, buf.value.decode(errors="replace")
 
     def counters(self):
         out = np.zeros(10)

@@ -171,8 +171,27 @@ void cholmod_mi355_select (cholmod_sparse *A, int for_whom, cholmod_factor *L, c
     }
     if (Common->useGPU == EMPTY)
     {
+        // not asked for, not forbidden: the environment decides, and with it come the memory limits
+        // (cholmod_super_symbolic.c:250-289)
         const char *env = getenv ("CHOLMOD_USE_GPU") ;
         Common->useGPU = (env && atoi (env) != 0) ? 1 : 0 ;
+        if (Common->useGPU == 1)
+        {
+            const char *env_bytes = getenv ("CHOLMOD_GPU_MEM_BYTES") ;
+            const char *env_fraction = getenv ("CHOLMOD_GPU_MEM_FRACTION") ;
+            if (env_bytes)
+            {
+                const long long b = atoll (env_bytes) ;
+                Common->maxGpuMemBytes = (b > 0) ? (size_t) b : 0 ;
+            }
+            if (env_fraction)
+            {
+                double f = atof (env_fraction) ;
+                if (f < 0) f = 0 ;
+                if (f > 1) f = 1 ;
+                Common->maxGpuMemFraction = f ;
+            }
+        }
     }
     if (Common->useGPU == 1) Common->useGPU = (mi355_probe ( ) > 0) ? 1 : 0 ;
     L->useGPU = Common->useGPU ;
@@ -214,6 +233,50 @@ static void gpu_problem (cholmod_common *Common, const char *file, int line)
     cholmod_l_error (CHOLMOD_GPU_PROBLEM, file, line, mi355_last_error ( ), Common) ;
 }
 
+// ---- soft fallback -----------------------------------------------------------------------------------------------
+// The reference never fails a factorization because of its GPU: gpu_init that cannot set itself up turns the GPU off for
+// the call and the CPU worker runs (t_cholmod_super_numeric_worker.c:233-244, CHOLMOD/GPU/t_cholmod_gpu.c:107-118), any
+// later gpu_* step that fails returns 0 and the CPU BLAS does that step (:755-759, :1007-1011, :1163-1166).  Here the
+// device takes a factorization whole or not at all: when the handle cannot be created (a factor larger than the memory
+// the device has free or Common->maxGpuMemBytes / maxGpuMemFraction allow, no device, an allocation that fails) or the
+// device run fails, L->useGPU goes to 0 for this factor and the unchanged CPU worker factorizes it.
+static int64_t fallbacks = 0 ;
+static char fallback_reason [512] = "" ;
+
+int64_t cholmod_mi355_fallbacks (char *reason, size_t len)
+{
+    pthread_mutex_lock (&table_lock) ;
+    const int64_t k = fallbacks ;
+    if (reason && len > 0)
+    {
+        strncpy (reason, fallback_reason, len - 1) ;
+        reason [len - 1] = '\0' ;
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (k) ;
+}
+
+static int soft_fallback (cholmod_sparse *A, double beta [2], cholmod_factor *L, cholmod_common *Common,
+    int unpermuted, int *ok)
+{
+    pthread_mutex_lock (&table_lock) ;
+    fallbacks++ ;
+    strncpy (fallback_reason, mi355_last_error ( ), sizeof (fallback_reason) - 1) ;
+    fallback_reason [sizeof (fallback_reason) - 1] = '\0' ;
+    pthread_mutex_unlock (&table_lock) ;
+    cholmod_mi355_forget (L) ;
+    L->useGPU = 0 ;
+    if (!unpermuted) return (FALSE) ;       // the wrapper's own switch runs the CPU worker on the S it was given
+    // cholmod_factorize_p handed over A itself (cholmod_mi355_defer_permutation): build S = tril (P*A*P') the way it
+    // would have (cholmod_factorize.c:228-238) and run the wrapper on it; its hook declines now (L->useGPU == 0)
+    cholmod_sparse *A2 = cholmod_l_ptranspose (A, 2, (int64_t *) L->Perm, NULL, 0, Common) ;
+    cholmod_sparse *S = (Common->status >= CHOLMOD_OK) ? cholmod_l_ptranspose (A2, 2, NULL, NULL, 0, Common) : NULL ;
+    cholmod_l_free_sparse (&A2, Common) ;
+    *ok = (S != NULL && Common->status >= CHOLMOD_OK) ? cholmod_l_super_numeric (S, NULL, beta, L, Common) : FALSE ;
+    cholmod_l_free_sparse (&S, Common) ;
+    return (TRUE) ;
+}
+
 int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2], cholmod_factor *L,
     cholmod_common *Common, int *ok)
 {
@@ -239,9 +302,18 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
     int rc = MI355_OK ;
     if (h == NULL)
     {
-        rc = mi355_factor_create (lx, (int64_t) L->n, (int64_t) L->nsuper, (const int64_t *) L->super,
-                (const int64_t *) L->pi, (const int64_t *) L->px, (const int64_t *) L->s,
-                (int64_t) L->ssize, (int64_t) L->xsize, /* device */ 0, &h) ;
+        // on the thread's current device, as the reference (cudaGetDevice, CHOLMOD/GPU/cholmod_gpu.c:165), within the
+        // memory Common allows (cholmod_gpu.c:446-489)
+        int device = 0 ;
+        rc = mi355_current_device (&device) ;
+        if (rc == MI355_OK)
+        {
+            rc = mi355_factor_create_limited (lx, (int64_t) L->n, (int64_t) L->nsuper, (const int64_t *) L->super,
+                    (const int64_t *) L->pi, (const int64_t *) L->px, (const int64_t *) L->s,
+                    (int64_t) L->ssize, (int64_t) L->xsize, device, (int64_t) Common->maxGpuMemBytes,
+                    (Common->maxGpuMemFraction > 0 && Common->maxGpuMemFraction <= 1) ? Common->maxGpuMemFraction : 0.0,
+                    NULL, &h) ;
+        }
         if (rc == MI355_OK && !remember_handle (L, h, lx))
         {
             mi355_factor_free (h) ;
@@ -290,16 +362,15 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
         if (rc == MI355_OK) rc = mi355_factor_numeric_host (h, beta [0], Common->quick_return_if_not_posdef,
                 (double *) L->x, &minor, &status) ;
     }
-    if (rc != MI355_OK)
+    if (rc == MI355_INVALID)
     {
-        // same policy as CHOLMOD_HANDLE_CUDA_ERROR (t_cholmod_gpu.c:74-82): report, do not hide
-        if (rc == MI355_OUT_OF_MEMORY) cholmod_l_error (CHOLMOD_OUT_OF_MEMORY, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
-        else if (rc == MI355_TOO_LARGE) cholmod_l_error (CHOLMOD_TOO_LARGE, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
-        else gpu_problem (Common, __FILE__, __LINE__) ;
+        // the arrays of A or L are not what the wrapper's checks promised: nothing a CPU run would cure
+        cholmod_l_error (CHOLMOD_INVALID, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
         cholmod_mi355_forget (L) ;
         *ok = FALSE ;
         return (TRUE) ;
     }
+    if (rc != MI355_OK) return (soft_fallback (A, beta, L, Common, unpermuted, ok)) ;
     {
         // BLAS statistics (cholmod.h:966-986, printed by cholmod_l_gpu_stats): here one GEMM launch is a batch of
         // fused SYRK + GEMM + assembly (or TRSM) tasks, so they are all booked under GEMM; times only with BLAS_TIMER
@@ -328,6 +399,18 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
 }
 
 // ---- triangular solves -------------------------------------------------------------------------------------------
+// a device sweep that cannot run (no memory for the right-hand sides, a failed launch) leaves the call to the host code,
+// whose input -- L->x -- is complete; the device image stays (the next call may fit)
+static int solve_fallback (void)
+{
+    pthread_mutex_lock (&table_lock) ;
+    fallbacks++ ;
+    strncpy (fallback_reason, mi355_last_error ( ), sizeof (fallback_reason) - 1) ;
+    fallback_reason [sizeof (fallback_reason) - 1] = '\0' ;
+    pthread_mutex_unlock (&table_lock) ;
+    return (FALSE) ;
+}
+
 int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, cholmod_common *Common, int *ok)
 {
     if (L->dtype != CHOLMOD_DOUBLE || L->itype != CHOLMOD_LONG || X->dtype != CHOLMOD_DOUBLE) return (FALSE) ;
@@ -337,12 +420,13 @@ int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, c
     if (h == NULL) return (FALSE) ;
     const int rc = lower ? mi355_super_lsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d)
                          : mi355_super_ltsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d) ;
-    if (rc != MI355_OK)
+    if (rc == MI355_INVALID)
     {
         gpu_problem (Common, __FILE__, __LINE__) ;
         *ok = FALSE ;
         return (TRUE) ;
     }
+    if (rc != MI355_OK) return (solve_fallback ( )) ;    // L->x on the host is complete: the CPU worker sweeps it
     count_taken (1) ;
     *ok = TRUE ;
     return (TRUE) ;
@@ -378,13 +462,13 @@ int cholmod_mi355_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_
         rc = mi355_solve_x (h, sys, (int64_t) B->ncol, B->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX,
                 (const double *) B->x, (int64_t) B->d, (double *) X->x, (int64_t) X->d) ;
     }
-    if (rc != MI355_OK)
+    if (rc == MI355_INVALID)
     {
-        if (rc == MI355_OUT_OF_MEMORY) cholmod_l_error (CHOLMOD_OUT_OF_MEMORY, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
-        else gpu_problem (Common, __FILE__, __LINE__) ;
+        gpu_problem (Common, __FILE__, __LINE__) ;
         *ok = FALSE ;
         return (TRUE) ;
     }
+    if (rc != MI355_OK) return (solve_fallback ( )) ;    // the host branch of cholmod_solve2 runs on L->x
     count_taken (2) ;
     *ok = TRUE ;
     return (TRUE) ;

@@ -88,6 +88,12 @@ struct DeviceSchedule {
     DevBuf<PotrfTask> sutasks;
     DevBuf<int32_t> stmap;
     DevBuf<SolveRange> sranges, sranges_mma;
+    // ... its wide path (many right-hand sides): one-block groups on lists of their own + SolveGroupUpd tasks
+    DevBuf<PotrfTask> snutasks;
+    DevBuf<int32_t> sntmap;
+    DevBuf<SolveRange> snranges_mma, swranges;
+    DevBuf<SolveGroupUpd> swtasks;
+    DevBuf<int32_t> swwg;
     bool solve_groups_ready = false;
 };
 
@@ -619,13 +625,51 @@ int mi355_probe(void)
     return usable;
 }
 
+int mi355_current_device(int *device)
+{
+    g_err.clear();
+    if (!device) return fail(MI355_INVALID, "null argument");
+    *device = 0;
+    HIP_TRY(hipGetDevice(device));
+    return MI355_OK;
+}
+
+int mi355_device_memory(int device, int64_t *total_bytes, int64_t *free_bytes)
+{
+    g_err.clear();
+    if (!total_bytes || !free_bytes) return fail(MI355_INVALID, "null argument");
+    *total_bytes = *free_bytes = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MI355_GPU_PROBLEM, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(MI355_INVALID, "device index out of range");
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    HIP_TRY(hipSetDevice(device));
+    size_t fr = 0, tot = 0;
+    const hipError_t e = hipMemGetInfo(&fr, &tot);
+    (void)hipSetDevice(cur);
+    HIP_TRY(e);
+    *total_bytes = (int64_t)tot; *free_bytes = (int64_t)fr;
+    return MI355_OK;
+}
+
 int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Super,
                         const int64_t *Lpi, const int64_t *Lpx, const int64_t *Ls,
                         int64_t ssize, int64_t xsize, int device, mi355_factor **handle)
 {
+    return mi355_factor_create_limited(xtype, n, nsuper, Super, Lpi, Lpx, Ls, ssize, xsize, device, 0, 0.0, nullptr, handle);
+}
+
+int mi355_factor_create_limited(int xtype, int64_t n, int64_t nsuper, const int64_t *Super,
+                                const int64_t *Lpi, const int64_t *Lpx, const int64_t *Ls,
+                                int64_t ssize, int64_t xsize, int device, int64_t max_bytes, double max_fraction,
+                                int64_t *needed_bytes, mi355_factor **handle)
+{
     g_err.clear();
+    if (needed_bytes) *needed_bytes = 0;
     if (!handle) return fail(MI355_INVALID, "null handle pointer");
     *handle = nullptr;
+    if (max_bytes < 0 || !(max_fraction >= 0.0 && max_fraction <= 1.0)) return fail(MI355_INVALID, "memory limit out of range");
     if (xtype != MI355_REAL && xtype != MI355_COMPLEX)
         return fail(MI355_INVALID, "factor xtype must be MI355_REAL or MI355_COMPLEX (a zomplex A gives a complex L)");
     if (n < 0 || nsuper < 0 || ssize < 0 || xsize < 0) return fail(MI355_INVALID, "negative size");
@@ -675,6 +719,31 @@ int mi355_factor_create(int xtype, int64_t n, int64_t nsuper, const int64_t *Sup
     F->sym.cplx = (F->E == 2);          // the big-tile kernel then covers 64 x 128 complex entries per tile
     build_schedule(F->sym, nsuper, 0, F->full.sched);
     pc.lap("build_schedule");
+    {
+        // Device memory of this handle, known before anything is allocated: the factor, the block inverses, the symbolic
+        // arrays and the schedule's tables (+ the transient pair list of k_relmap).  The reference sizes its pool from
+        // Common->maxGpuMemBytes / maxGpuMemFraction and leaves 50 MB to the driver (CHOLMOD/GPU/cholmod_gpu.c:446-489);
+        // here the same knobs cap what a handle may take, and a factor that does not fit is refused as a whole instead
+        // of failing half-way through its allocations.
+        const Schedule &sc = F->full.sched;
+        const double need = 8.0 * F->E * ((double)xsize + (double)sc.dinv_size) + 4.0 * (double)nls + 4.0 * (double)n
+            + 24.0 * (double)(nsuper + 1) + 4.0 * (double)(nsuper + 2)
+            + (double)sizeof(GemmTask) * sc.gemm.size() + (double)sizeof(PotrfTask) * sc.potrf.size()
+            + 4.0 * sc.potrf_order.size() + (double)sizeof(Schedule::TileEntry) * sc.gemm_tile_tab.size()
+            + 4.0 * sc.solve_tile_task.size() + 4.0 * (double)sc.relmap_size + (double)sizeof(RelmapPair) * sc.pairs.size();
+        if (needed_bytes) *needed_bytes = (int64_t)need;
+        size_t fr = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &tot));
+        double limit = (double)fr - 50.0 * 1024 * 1024;
+        if (max_bytes > 0) limit = std::min(limit, (double)max_bytes);
+        if (max_fraction > 0.0) limit = std::min(limit, max_fraction * (double)tot);
+        if (need > limit) {
+            char b[256];
+            snprintf(b, sizeof b, "device memory: the factor needs %.0f MB, %.0f MB may be used (free %.0f MB, limits %lld bytes / fraction %g)",
+                     need / 1048576.0, std::max(0.0, limit) / 1048576.0, (double)fr / 1048576.0, (long long)max_bytes, max_fraction);
+            return fail(MI355_OUT_OF_MEMORY, b);
+        }
+    }
 
     // device copies of the symbolic arrays (row indices narrowed to int32)
     std::vector<int32_t> ls32((size_t)nls);
@@ -1428,7 +1497,7 @@ double *mi355_factor_device_Dinv(mi355_factor *F) { return F ? F->Dinv.p : nullp
 static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
 {
     if (DS.solve_groups_ready) return MI355_OK;
-    build_solve_groups(DS.sched, DS.ssched);
+    build_solve_groups(DS.sched, DS.ssched, F->E == 2 ? 128 : 256);
     {
         const Schedule none;                           // tasks already checked at upload: only the solve work lists here
         const std::string bad = check_schedule_bounds(F->sym, none, &DS.ssched,
@@ -1440,6 +1509,12 @@ static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
     HIP_TRY(DS.stmap.upload(DS.ssched.tile_task.data(), DS.ssched.tile_task.size(), F->stream));
     HIP_TRY(DS.sranges.upload(DS.ssched.ranges.data(), DS.ssched.ranges.size(), F->stream));
     HIP_TRY(DS.sranges_mma.upload(DS.ssched.ranges_mma.data(), DS.ssched.ranges_mma.size(), F->stream));
+    HIP_TRY(DS.snutasks.upload(DS.ssched.nutasks.data(), DS.ssched.nutasks.size(), F->stream));
+    HIP_TRY(DS.sntmap.upload(DS.ssched.ntile_task.data(), DS.ssched.ntile_task.size(), F->stream));
+    HIP_TRY(DS.snranges_mma.upload(DS.ssched.nranges_mma.data(), DS.ssched.nranges_mma.size(), F->stream));
+    HIP_TRY(DS.swtasks.upload(DS.ssched.wtasks.data(), DS.ssched.wtasks.size(), F->stream));
+    HIP_TRY(DS.swranges.upload(DS.ssched.wranges.data(), DS.ssched.wranges.size(), F->stream));
+    HIP_TRY(DS.swwg.upload(DS.ssched.wwg.data(), DS.ssched.wwg.size(), F->stream));
     DS.solve_groups_ready = true;
     return MI355_OK;
 }
@@ -1551,22 +1626,61 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
 #undef MI355_SGM_MB
 #undef MI355_SGM
             };
-            const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_fwd_div_mma)));
-            const unsigned grid = (unsigned)((st.stiles + group - 1) / group);
+            // wide path (tuning key 23, on): groups of one block keep the per-block kernels (lists of their own), the rows
+            // below a wider group take all its columns in one pass (k_solve_fwd_wide / k_solve_bwd_wide)
+            const bool wide = tuning().solve_wide && DS.ssched.kmax > 0;
+            if (wide && st.wrcount > 0) {
+                // MI355_SOLVE_LOG=file: one line per wide launch -- sweep, workgroups, bytes of L it reads, tasks, widest task
+                // (analysis runs: the lines are in launch order, as the kernel trace is)
+                static FILE *slog = [] { const char *fn = getenv("MI355_SOLVE_LOG"); return fn ? fopen(fn, "w") : (FILE *)nullptr; }();
+                if (slog) {
+                    double bytes = 0; int64_t rows = 0;
+                    for (int64_t u = 0; u < st.wcount; u++) {
+                        const SolveGroupUpd &wt = DS.ssched.wtasks[(size_t)(st.wfirst + u)];
+                        bytes += 8.0 * F->E * (double)wt.nrows * wt.ncols; rows = std::max<int64_t>(rows, wt.nrows);
+                    }
+                    fprintf(slog, "%s wgs %lld bytes %.0f tasks %lld maxrows %lld maxblk %d\n", lower ? "fwd" : "bwd",
+                            (long long)st.wgcount, bytes, (long long)st.wcount, (long long)rows, st.wmaxblk);
+                    fflush(slog);
+                }
+            }
+            const int64_t ptiles = wide ? st.nstiles : st.stiles;
+            const PotrfTask *ptasks = wide ? DS.snutasks.p + st.nufirst : DS.sutasks.p + st.ufirst;
+            const int32_t *ptmap = wide ? DS.sntmap.p + st.ntmap_off : DS.stmap.p + st.tmap_off;
+            const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, ptiles / std::max(1, tuning().solve_fwd_div_mma)));
+            const unsigned grid = (unsigned)((ptiles + group - 1) / group);
+            const int wnj = 64 * F->E;                  // real columns of Y per pass of the wide kernels
+            if (wide && st.wrcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
             if (lower) {
                 group_kernel();
-                if (st.stiles > 0)
+                if (ptiles > 0)
                     for (int j0 = 0; j0 < nrr; j0 += 64)
                         hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           DS.sutasks.p + st.ufirst, DS.stmap.p + st.tmap_off, st.stiles, group,
-                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                                           ptasks, ptmap, ptiles, group, F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                if (wide && st.wrcount > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += wnj) {
+#define MI355_WIDE(K) hipLaunchKernelGGL(K, dim3((unsigned)st.wgcount), dim3(WIDE_THREADS), 0, F->stream, \
+                                         DS.swtasks.p + st.wfirst, DS.swranges.p + st.wrfirst, DS.swwg.p + st.wgfirst, \
+                                         F->Lx.p, F->dLs.p, X, d, nrr, j0)
+                        if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2>));
+                        else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2>));
+                        else MI355_WIDE((k_solve_fwd_wide<1, 4>));
+                    }
             } else {
-                if (st.rmcount > 0) {
-                    if (st.rmcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
+                const int64_t prcount = wide ? st.nrmcount : st.rmcount;
+                const SolveRange *pruns = wide ? DS.snranges_mma.p + st.nrmfirst : DS.sranges_mma.p + st.rmfirst;
+                if (wide && st.wrcount > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += wnj) {
+                        if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2>));
+                        else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_bwd_wide<1, 2>));
+                        else MI355_WIDE((k_solve_bwd_wide<1, 4>));
+#undef MI355_WIDE
+                    }
+                if (prcount > 0) {
+                    if (prcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
                     for (int j0 = 0; j0 < nrr; j0 += 64)
-                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma_run<2> : k_solve_bwd_mma_run<1>, dim3((unsigned)st.rmcount),
-                                           dim3(256), 0, F->stream, DS.sutasks.p + st.ufirst, DS.sranges_mma.p + st.rmfirst,
-                                           F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                        hipLaunchKernelGGL(cplx ? k_solve_bwd_mma_run<2> : k_solve_bwd_mma_run<1>, dim3((unsigned)prcount),
+                                           dim3(256), 0, F->stream, ptasks, pruns, F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 }
                 group_kernel();
             }
@@ -1877,8 +1991,10 @@ int mi355_solve_x(mi355_factor *F, int sys, int64_t nrhs, int bxtype, const doub
     // device images of B and X, kept by the handle from call to call (cholmod_solve2's Y / E workspaces play that part
     // in the reference, cholmod_solve.c:119-153)
     const size_t need_b = (size_t)n * nrhs * Eb, need_x = (size_t)n * nrhs * Ex;
-    if (F->solve_b_cap < need_b) { HIP_TRY(F->solve_b.alloc(need_b)); F->solve_b_cap = need_b; }
-    if (F->solve_x_cap < need_x) { HIP_TRY(F->solve_x.alloc(need_x)); F->solve_x_cap = need_x; }
+    // alloc() releases the old buffer first: the recorded capacity goes to zero before the attempt and is set again only
+    // on success, so that after an out-of-memory failure a later, smaller request allocates afresh (as Ywork does)
+    if (F->solve_b_cap < need_b) { F->solve_b_cap = 0; HIP_TRY(F->solve_b.alloc(need_b)); F->solve_b_cap = need_b; }
+    if (F->solve_x_cap < need_x) { F->solve_x_cap = 0; HIP_TRY(F->solve_x.alloc(need_x)); F->solve_x_cap = need_x; }
     double *dB = F->solve_b.p, *dX = F->solve_x.p;
     const bool staged = need_b * sizeof(double) >= ((size_t)std::max(0, tuning().host_staged_min_kb) << 10);   // small ones: not worth the threads
     if (staged) {
@@ -1973,6 +2089,8 @@ int mi355_set_tuning(int key, int value)
     else if (key == 20) tuning().host_lanes = std::max(1, value);
     else if (key == 21) tuning().host_lane_mb = std::max(1, value);
     else if (key == 22) tuning().host_staged_min_kb = std::max(0, value);
+    else if (key == 23) tuning().solve_wide = value ? 1 : 0;
+    else if (key == 24) tuning().solve_wide_wgs = std::max(1, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -547,9 +547,10 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     }
 }
 
-void build_solve_groups(const Schedule &sc, SolveSchedule &out)
+void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
 {
     out = SolveSchedule();
+    out.kmax = kmax;
     // the POTRF steps of one level are its iterations it = 0, 1, 2, ... in order; iteration it holds the
     // block at columns [NB*it, NB*it + nb) of every supernode of the level that is that wide
     size_t i = 0;
@@ -568,6 +569,10 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
             st.ufirst = (int64_t)out.utasks.size(); st.ucount = 0;
             st.stiles = 0; st.tmap_off = (int64_t)out.tile_task.size();
             st.maxblk = 1; st.pad = 0;
+            st.nufirst = (int64_t)out.nutasks.size(); st.nucount = 0;
+            st.nstiles = 0; st.ntmap_off = (int64_t)out.ntile_task.size();
+            st.wfirst = (int64_t)out.wtasks.size(); st.wcount = 0;
+            st.wmaxblk = 1; st.pad2 = 0;
             // groups: one per supernode present at the first iteration of the range
             std::vector<std::pair<int32_t, int64_t>> by_s;         // (supernode, group index), sorted by supernode
             const Step &f = *its[g0];
@@ -615,6 +620,32 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
                     out.tile_task.insert(out.tile_task.end(), (size_t)nt, (int32_t)st.ucount);
                     out.utasks.push_back(pt);
                     st.ucount++;
+                    if (kmax > 0 && gt.ncols <= NB) {
+                        // a group of one block: the per-block kernels, on the lists of the wide path
+                        pt.stile0 = st.nstiles;
+                        st.nstiles += nt;
+                        out.ntile_task.insert(out.ntile_task.end(), (size_t)nt, (int32_t)st.nucount);
+                        out.nutasks.push_back(pt);
+                        st.nucount++;
+                    }
+                }
+                if (kmax > 0 && gt.ncols > NB && !blocks[(size_t)gi].empty()) {
+                    const PotrfTask &p0 = blocks[(size_t)gi][0];
+                    const int32_t gcol0 = gt.x0 - p0.k1;
+                    const int32_t below = p0.lda - (gcol0 + gt.ncols);
+                    for (int32_t c0 = 0; below > 0 && c0 < gt.ncols; c0 += kmax) {
+                        SolveGroupUpd wt;
+                        wt.lda = p0.lda;
+                        wt.ncols = std::min<int32_t>(kmax, gt.ncols - c0);
+                        wt.x0 = gt.x0 + c0;
+                        wt.nrows = below;
+                        // gt.a_off = L[gcol0][gcol0]; the first row below the group is local row gcol0 + ncols
+                        wt.a_off = gt.a_off + gt.ncols + (int64_t)c0 * p0.lda;
+                        wt.ls_off = p0.ls_off + gcol0 + gt.ncols;
+                        st.wmaxblk = std::max<int32_t>(st.wmaxblk, (wt.ncols + NB - 1) / NB);
+                        out.wtasks.push_back(wt);
+                        st.wcount++;
+                    }
                 }
             }
             // backward sweep: runs of at most `run` tiles, long enough to amortise the flush (a transpose-reduce
@@ -636,6 +667,59 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out)
             st.rmfirst = (int64_t)out.ranges_mma.size();
             cut(out.ranges_mma, std::min<int64_t>(16, std::max<int64_t>(1, st.stiles / std::max(1, tuning().solve_bwd_div_mma))));
             st.rmcount = (int64_t)out.ranges_mma.size() - st.rmfirst;
+            st.nrmfirst = (int64_t)out.nranges_mma.size(); st.nrmcount = 0;
+            st.wrfirst = (int64_t)out.wranges.size(); st.wrcount = 0;
+            if (kmax > 0) {
+                const int64_t run = std::min<int64_t>(16, std::max<int64_t>(1, st.nstiles / std::max(1, tuning().solve_bwd_div_mma)));
+                for (int64_t u = 0; u < st.nucount; u++) {
+                    const PotrfTask &pt = out.nutasks[(size_t)(st.nufirst + u)];
+                    const int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                    for (int64_t t0 = 0; t0 < nt; t0 += run)
+                        out.nranges_mma.push_back({(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(run, nt - t0), 0});
+                }
+                st.nrmcount = (int64_t)out.nranges_mma.size() - st.nrmfirst;
+                // wide tasks: one workgroup per CU (the x1 image of a whole group fills the LDS), so the tiles of the step
+                // -- weighted by the columns of their task -- are dealt in order to at most solve_wide_wgs workgroups,
+                // each a contiguous share that may run over task boundaries (a segment per task; at most WIDE_MAX_RUN = 64
+                // tiles per segment, the kernels' row list in LDS).  Cutting every task into runs of one length left the
+                // workgroups of a step with 1 : 6 different loads and two rounds of them on the chip.
+                double wtotal = 0;
+                for (int64_t u = 0; u < st.wcount; u++) {
+                    const SolveGroupUpd &wt = out.wtasks[(size_t)(st.wfirst + u)];
+                    wtotal += (double)((wt.nrows + 63) / 64) * wt.ncols;
+                }
+                int64_t wt64 = 0;
+                for (int64_t u = 0; u < st.wcount; u++) wt64 += (out.wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
+                const int64_t G = std::max<int64_t>(1, std::min<int64_t>(tuning().solve_wide_wgs, wt64));
+                st.wgfirst = (int64_t)out.wwg.size(); st.wgcount = 0;
+                if (st.wcount > 0) {
+                    out.wwg.push_back(0);
+                    double done = 0;                    // weight dealt so far
+                    int64_t g = 0;                      // workgroup being filled
+                    for (int64_t u = 0; u < st.wcount; u++) {
+                        const SolveGroupUpd &wt = out.wtasks[(size_t)(st.wfirst + u)];
+                        const int64_t nt = (wt.nrows + 63) / 64;
+                        int64_t t0 = 0;
+                        while (t0 < nt) {
+                            // tiles of this task that still fit workgroup g: up to its share's end, at least one
+                            const double end = wtotal * (double)(g + 1) / (double)G;
+                            int64_t fit = (int64_t)((end - done) / wt.ncols + 0.5);
+                            fit = std::max<int64_t>(1, std::min<int64_t>(fit, std::min<int64_t>(nt - t0, 64)));
+                            out.wranges.push_back({(int32_t)u, (int32_t)t0, (int32_t)fit, 0});
+                            t0 += fit;
+                            done += (double)fit * wt.ncols;
+                            if (done >= end - 0.5 * wt.ncols && g + 1 < G) {
+                                out.wwg.push_back((int32_t)((int64_t)out.wranges.size() - st.wrfirst));
+                                g++;
+                            }
+                        }
+                    }
+                    if (out.wwg.back() != (int32_t)((int64_t)out.wranges.size() - st.wrfirst))
+                        out.wwg.push_back((int32_t)((int64_t)out.wranges.size() - st.wrfirst));
+                    st.wgcount = (int64_t)out.wwg.size() - st.wgfirst - 1;
+                }
+                st.wrcount = (int64_t)out.wranges.size() - st.wrfirst;
+            }
             out.steps.push_back(st);
         }
     }
@@ -883,6 +967,70 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
             }
             if (covered != st.stiles) return bad("solve step run coverage", (int64_t)i);
         }
+        if (ss->kmax <= 0) continue;
+        // the wide path's lists: one-block groups on per-block tasks of their own, wider groups as SolveGroupUpd
+        if (st.nufirst < 0 || st.nufirst + st.nucount > (int64_t)ss->nutasks.size()) return bad("solve step narrow tasks", (int64_t)i);
+        if (st.ntmap_off < 0 || st.ntmap_off + st.nstiles > (int64_t)ss->ntile_task.size()) return bad("solve step narrow tiles", (int64_t)i);
+        if (st.wfirst < 0 || st.wfirst + st.wcount > (int64_t)ss->wtasks.size()) return bad("solve step wide tasks", (int64_t)i);
+        if (st.wmaxblk < 1 || st.wmaxblk * NB > std::max<int32_t>(ss->kmax, NB)) return bad("solve step wide depth", (int64_t)i);
+        tiles = 0;
+        for (int64_t u = 0; u < st.nucount; u++) {
+            const PotrfTask &t = ss->nutasks[(size_t)(st.nufirst + u)];
+            if (t.stile0 != tiles) return bad("solve step narrow tile prefix", (int64_t)i);
+            tiles += ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+        }
+        if (tiles != st.nstiles) return bad("solve step narrow tile count", (int64_t)i);
+        for (int64_t b = 0; b < st.nstiles; b++) {
+            const int32_t ti = ss->ntile_task[(size_t)(st.ntmap_off + b)];
+            if (ti < 0 || ti >= st.nucount) return bad("solve step narrow tile entry", (int64_t)i);
+        }
+        if (st.nrmfirst < 0 || st.nrmfirst + st.nrmcount > (int64_t)ss->nranges_mma.size()) return bad("solve step narrow runs", (int64_t)i);
+        int64_t ncovered = 0;
+        for (int64_t k = st.nrmfirst; k < st.nrmfirst + st.nrmcount; k++) {
+            const SolveRange &e = ss->nranges_mma[(size_t)k];
+            if (e.task < 0 || e.task >= st.nucount || e.tile0 < 0 || e.ntiles <= 0) return bad("solve narrow run", k);
+            const PotrfTask &t = ss->nutasks[(size_t)(st.nufirst + e.task)];
+            if (e.tile0 + e.ntiles > ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS) return bad("solve narrow run tiles", k);
+            ncovered += e.ntiles;
+        }
+        if (ncovered != st.nstiles) return bad("solve step narrow run coverage", (int64_t)i);
+        if (st.wrfirst < 0 || st.wrfirst + st.wrcount > (int64_t)ss->wranges.size()) return bad("solve step wide runs", (int64_t)i);
+        int64_t wcovered = 0, wtotal = 0;
+        for (int64_t u = 0; u < st.wcount; u++) wtotal += ((int64_t)ss->wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
+        for (int64_t k = st.wrfirst; k < st.wrfirst + st.wrcount; k++) {
+            const SolveRange &e = ss->wranges[(size_t)k];
+            if (e.task < 0 || e.task >= st.wcount || e.tile0 < 0 || e.ntiles <= 0 || e.ntiles > 64) return bad("solve wide run", k);   // 64 = WIDE_MAX_RUN (the kernels' row list in LDS)
+            if (e.tile0 + e.ntiles > ((int64_t)ss->wtasks[(size_t)(st.wfirst + e.task)].nrows + 63) / 64) return bad("solve wide run tiles", k);
+            wcovered += e.ntiles;
+        }
+        if (wcovered != wtotal) return bad("solve step wide run coverage", (int64_t)i);
+        // every segment belongs to exactly one workgroup, in order; segments of one task are consecutive and in order
+        if (st.wcount > 0) {
+            if (st.wgfirst < 0 || st.wgcount <= 0 || st.wgfirst + st.wgcount + 1 > (int64_t)ss->wwg.size()) return bad("solve step workgroup table", (int64_t)i);
+            if (ss->wwg[(size_t)st.wgfirst] != 0 || ss->wwg[(size_t)(st.wgfirst + st.wgcount)] != st.wrcount) return bad("solve step workgroup table ends", (int64_t)i);
+            for (int64_t g = 0; g < st.wgcount; g++)
+                if (ss->wwg[(size_t)(st.wgfirst + g)] >= ss->wwg[(size_t)(st.wgfirst + g + 1)]) return bad("solve step workgroup share", (int64_t)i);
+            int64_t task = -1, next_tile = 0;
+            for (int64_t k = st.wrfirst; k < st.wrfirst + st.wrcount; k++) {
+                const SolveRange &e = ss->wranges[(size_t)k];
+                if (e.task != task) { if (e.task != task + 1 && !(task < 0)) { /* tasks without rows do not exist */ } task = e.task; next_tile = 0; }
+                if (e.tile0 != next_tile) return bad("solve wide segment order", k);
+                next_tile += e.ntiles;
+            }
+        } else if (st.wrcount != 0) return bad("solve step wide runs without tasks", (int64_t)i);
+    }
+    for (size_t i = 0; i < ss->nutasks.size(); i++) {
+        const PotrfTask &t = ss->nutasks[i];
+        if (t.nb <= 0 || t.nb > NB || t.urow0 < t.col0 + t.nb || t.urow0 > t.lda) return bad("solve narrow task shape", (int64_t)i);
+        if (t.a_off < 0 || last(t.a_off, (int64_t)t.lda - t.col0, t.nb, t.lda) >= xs) return bad("solve narrow task L", (int64_t)i);
+        if (t.ls_off < 0 || t.ls_off + t.lda > ssz || (int64_t)t.k1 + t.col0 + t.nb > S.n) return bad("solve narrow task rows", (int64_t)i);
+    }
+    for (size_t i = 0; i < ss->wtasks.size(); i++) {
+        const SolveGroupUpd &t = ss->wtasks[i];
+        if (t.ncols <= 0 || t.ncols > ss->kmax || t.nrows <= 0 || t.lda < t.nrows) return bad("solve wide task shape", (int64_t)i);
+        if (t.a_off < 0 || last(t.a_off, t.nrows, t.ncols, t.lda) >= xs) return bad("solve wide task L", (int64_t)i);
+        if (t.ls_off < 0 || t.ls_off + t.nrows > ssz) return bad("solve wide task rows", (int64_t)i);
+        if (t.x0 < 0 || (int64_t)t.x0 + t.ncols > S.n) return bad("solve wide task rows of X", (int64_t)i);
     }
     return "";
 }

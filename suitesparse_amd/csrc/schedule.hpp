@@ -76,6 +76,20 @@ struct SolveGroupTask {
     int32_t pad;
 };
 struct SolveRange { int32_t task, tile0, ntiles, pad; };   // a run of row tiles of one update task (backward sweep)
+// Many right-hand sides (round 3): the rows below a solve group take the update of ALL the group's columns in one
+// pass (contraction depth up to 256 columns, 128 for a complex factor) instead of one pass per 64-column block, so
+// the 64 x nrhs rows of Y that a row tile touches cross HBM once per group, not once per block (measured in round 2:
+// the per-block kernels moved twice the algorithmic bytes, half of them rows of Y).  One "wide" task per group of
+// more than 64 columns (two when a complex group exceeds 128 columns); groups of one block keep the per-block
+// kernels, which hold four workgroups per CU where the wide kernels (x1 of the whole group in LDS) hold one.
+struct SolveGroupUpd {
+    int64_t a_off;      // entry offset of L[first row below the group][first column of the task]
+    int64_t ls_off;     // index into Ls of the first row below the group
+    int32_t lda;        // = nsrow
+    int32_t ncols;      // columns of the task (<= SolveSchedule::kmax)
+    int32_t x0;         // first row of X the task's columns own
+    int32_t nrows;      // rows below the group
+};
 struct SolveStep {
     int64_t gfirst, gcount;             // group tasks
     int64_t ufirst, ucount;             // per-block update tasks (PotrfTask with urow0 = end of the group)
@@ -83,6 +97,16 @@ struct SolveStep {
     int32_t maxblk, pad;                // most 64-column blocks of any group of the step
     int64_t rfirst, rcount;             // runs of row tiles for the backward sweep (scalar kernels)
     int64_t rmfirst, rmcount;           // ... for the MFMA kernel (shorter: it holds fewer workgroups per CU)
+    // wide path (many right-hand sides): the same rows, split into the groups of one block (per-block kernels on
+    // lists of their own) and the wider groups (SolveGroupUpd tasks, runs of 64-row tiles)
+    int64_t nufirst, nucount;           // per-block update tasks of the one-block groups (in nutasks)
+    int64_t nstiles, ntmap_off;         // their row tiles (in ntile_task)
+    int64_t nrmfirst, nrmcount;         // their runs for the backward MFMA kernel (in nranges_mma)
+    int64_t wfirst, wcount;             // wide tasks (in wtasks)
+    int64_t wrfirst, wrcount;           // segments (runs of 64-row tiles of one task) over them (in wranges; task relative to wfirst)
+    int64_t wgfirst, wgcount;           // the step's workgroups: wwg[wgfirst + g] .. wwg[wgfirst + g + 1] = segments of workgroup g
+                                        // (relative to wrfirst; wgcount + 1 offsets)
+    int32_t wmaxblk, pad2;              // most 64-column blocks of any wide task of the step
 };
 struct SolveSchedule {
     std::vector<SolveGroupTask> groups;
@@ -90,6 +114,13 @@ struct SolveSchedule {
     std::vector<int32_t> tile_task;
     std::vector<SolveRange> ranges, ranges_mma;
     std::vector<SolveStep> steps;       // forward order
+    int32_t kmax = 0;                   // contraction depth of the wide tasks (0: wide lists not built)
+    std::vector<PotrfTask> nutasks;
+    std::vector<int32_t> ntile_task;
+    std::vector<SolveRange> nranges_mma;
+    std::vector<SolveGroupUpd> wtasks;
+    std::vector<SolveRange> wranges;
+    std::vector<int32_t> wwg;
 };
 
 // one (descendant d -> ancestor s) update, the unit of a3.4 in SURVEY.md section 8
@@ -214,10 +245,10 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
 
 // the grouped solve sweep over the POTRF steps of sc (any schedule: full, or one part of a partition)
 struct Schedule;
-void build_solve_groups(const Schedule &sc, SolveSchedule &out);
+void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax = 0 /* 256 real, 128 complex; 0: no wide lists */);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -973,4 +973,321 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
     }
 }
 
+//------------------------------------------------------------------------------
+// Wide sweeps (round 3): the rows below a solve group take the update of ALL the group's columns in one pass.
+// The per-block kernels above touch the 64 x nrhs rows of Y of a row tile once per 64 columns of L: at nrhs = 64 a
+// 32 KB tile of L moves 32 KB of Y in and 32 KB out, and the counters showed twice the algorithmic bytes per sweep
+// (profiles/r02_pmc_traffic_solve64_lap3d150.txt).  Here the contraction runs over up to 256 columns (real; 128
+// complex, all 2 x 64 real columns of Y in one pass, so a complex L is also read once instead of twice):
+//   forward  k_solve_fwd_wide: x1 of the whole task (ncols x NJ) staged in LDS once per workgroup; every wave
+//            streams 16-row slabs of L straight into MFMA operand layout through a ring of two register sets (the
+//            next chunk of 64 columns is in flight while the current one is multiplied) and sends ONE set of
+//            atomics per slab;
+//   backward k_solve_bwd_wide: the products of a run of row tiles accumulate in registers for all the columns of the
+//            task; L goes through LDS (global loads with lanes along the rows: whole cache lines, where the
+//            per-block kernel read 32-byte runs), double-buffered per 64-column block, the gathered rows of Y are
+//            fetched once per row tile and serve all the blocks.
+// Complex L: P = Re(L) Y and Q = Im(L) Y accumulate separately against the SAME image of Y (Y as 2 nrhs real
+// columns) and are combined between neighbouring lanes at the end (no pair-swapped second image):
+//   L x   : (re, im) = (P_re - Q_im, P_im + Q_re);    L^H x : (re, im) = (P_re + Q_im, P_im - Q_re).
+// 512 threads, one workgroup per CU (LDS), two waves per SIMD.
+//------------------------------------------------------------------------------
+constexpr int WIDE_THREADS = 512;
+constexpr int WIDE_MAX_RUN = 64;          // most 64-row tiles of a run (build_solve_groups cuts the runs accordingly)
+
+// The hot loops of both kernels are free of per-entry conditions (a guarded load or MFMA becomes a branch of its own
+// and the compiler then waits for every load right where it is issued): addresses are clamped into the task (rows past
+// its end, columns past its width, right-hand sides past nrr read valid entries), what must not count is multiplied
+// by zeros of the LDS images or left out of the atomics.
+// v or +0.0, without a select on the loaded value: the compiler turns "cond ? load : 0" back into a guarded load (a branch
+// and a full wait per entry), a bit mask keeps the load unconditional
+__device__ __forceinline__ double keep_if(double v, bool keep)
+{
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    u &= keep ? ~0ull : 0ull;
+    __builtin_memcpy(&v, &u, 8);
+    return v;
+}
+
+template <int E, int KB>
+__global__ __launch_bounds__(WIDE_THREADS) void k_solve_fwd_wide(
+    const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
+    int nrr, int j0)
+{
+    constexpr int NJ = 64 * E;            // real columns of Y per pass
+    constexpr int NJB = NJ / 16;
+    constexpr int LD = KB * 64 + 2;       // LDS row stride: 16 j x 2 k of a half-wave on 32 disjoint bank pairs
+    constexpr int QC = 16 / E;            // k-steps (of 4 columns) per chunk of the operand ring
+    constexpr int NW = WIDE_THREADS / 64;
+    __shared__ double Xs[NJ][LD];         // Xs[j][c] = x1[c][j0 + j]
+    __shared__ int32_t rows_s[WIDE_MAX_RUN * 64];   // rows of Y the run updates (a load from Ls inside the loop would make
+                                                    // the wave wait for every operand request that is in flight)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nj = min(NJ, nrr - j0);
+    // the workgroup's share of the step: consecutive segments (runs of row tiles of one task) of the work list
+    for (int seg = wg_first[blockIdx.x]; seg < wg_first[blockIdx.x + 1]; seg++) {
+    const SolveRange e = work[seg];
+    const SolveGroupUpd t = tasks[e.task];
+    const int ncols = t.ncols, nq = (ncols + 3) >> 2;            // k-steps that hold anything
+    const int ncq = (nq + QC - 1) / QC;                           // chunks per slab
+    const int row0 = e.tile0 * 64;                                // first row (below the group) of the run
+    const int rows_run = min(64 * min(e.ntiles, WIDE_MAX_RUN), t.nrows - row0);
+    for (int i = tid; i < rows_run; i += WIDE_THREADS) rows_s[i] = Ls[t.ls_off + row0 + i];
+    const int nslab = (rows_run + 15) >> 4;
+    const int nmine = nslab > w ? (nslab - w + NW - 1) / NW : 0;  // slabs w, w + NW, ...
+    const int nch = nmine * ncq;
+    double a0[QC * E], a1[QC * E];
+    // chunk ch = (slab si, k-steps [QC cc, QC cc + QC)): this lane's entries L[row][4 q + lane/16]
+    auto chunk_ptr = [&](int ch, int &q0) -> const double * {
+        const int si = ch / ncq;
+        q0 = (ch - si * ncq) * QC;
+        const int r = min(row0 + (w + NW * si) * 16 + l15, t.nrows - 1);
+        return Lx + (t.a_off + r) * E;
+    };
+    auto load1 = [&](double (&a)[QC * E], const double *__restrict__ base, int q0, int qq) {
+        const int c = min(4 * (q0 + qq) + l4, ncols - 1);
+        if constexpr (E == 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)c * t.lda * 2);
+            a[2 * qq] = v.x; a[2 * qq + 1] = v.y;
+        } else {
+            a[qq] = base[(int64_t)c * t.lda];
+        }
+    };
+    // the first two chunks are requested before x1 is staged: their latency runs under the staging
+    {
+        int q0; const double *b0 = chunk_ptr(0, q0);
+#pragma unroll
+        for (int qq = 0; qq < QC; qq++) load1(a0, b0, q0, qq);
+        const double *b1 = chunk_ptr(nch > 1 ? 1 : 0, q0);
+#pragma unroll
+        for (int qq = 0; qq < QC; qq++) load1(a1, b1, q0, qq);
+    }
+    {
+        // x1 of the task, zero beyond its columns (up to the end of the last chunk) and beyond the right-hand sides;
+        // batches of 8 independent requests per lane (one request per pass of a plain loop costs a memory latency each)
+        const double *__restrict__ x1 = Y + (int64_t)t.x0 * ldr + j0;
+        const int units = NJB * ncq * QC;
+        for (int u0 = w; u0 < units; u0 += 8 * NW) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int u = min(u0 + NW * i, units - 1);
+                const int jb = u % NJB, c = 4 * (u / NJB) + l4, j = 16 * jb + l15;
+                v[i] = x1[(int64_t)min(c, ncols - 1) * ldr + min(j, nj - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int u = u0 + NW * i;
+                const int jb = u % NJB, c = 4 * (u / NJB) + l4, j = 16 * jb + l15;
+                if (u < units) Xs[j][c] = keep_if(v[i], c < ncols && j < nj);
+            }
+        }
+    }
+    __syncthreads();
+    v4d P[NJB], Q[E == 2 ? NJB : 1];
+#pragma unroll
+    for (int jb = 0; jb < NJB; jb++) { P[jb] = (v4d){0.0, 0.0, 0.0, 0.0}; if constexpr (E == 2) Q[jb] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+    // chunk ch from register set a; with AGAIN its registers are re-loaded for chunk ch + 2 as they are consumed
+    auto run_chunk = [&](double (&a)[QC * E], int ch, auto again_tag) {
+        constexpr bool AGAIN = decltype(again_tag)::value;
+        const int si = ch / ncq, cc = ch - si * ncq;
+        int q2 = 0;
+        const double *__restrict__ p2 = AGAIN ? chunk_ptr(ch + 2, q2) : nullptr;
+        const double *__restrict__ xs = &Xs[l15][4 * cc * QC + l4];
+#pragma unroll
+        for (int qq = 0; qq < QC; qq++) {
+#pragma unroll
+            for (int jb = 0; jb < NJB; jb++) {
+                const double b = xs[16 * jb * LD + 4 * qq];
+                if constexpr (E == 2) {
+                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq], b, P[jb], 0, 0, 0);
+                    Q[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq + 1], b, Q[jb], 0, 0, 0);
+                } else {
+                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qq], b, P[jb], 0, 0, 0);
+                }
+            }
+            if constexpr (AGAIN) load1(a, p2, q2, qq);
+        }
+        if (cc == ncq - 1) {
+            // the slab is complete: rows rbase + lane/16 + 4g (g = 0..3), real column 16 jb + lane%16
+            const int rbase = row0 + (w + NW * si) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int rr = rbase + l4 + 4 * g;
+                const bool okr = rr < t.nrows;
+                const int64_t row = (int64_t)rows_s[min(rr - row0, rows_run - 1)];
+                double *__restrict__ yp = Y + row * ldr + j0 + l15;
+#pragma unroll
+                for (int jb = 0; jb < NJB; jb++) {
+                    double v = P[jb][g];
+                    if constexpr (E == 2) {
+                        const double qx = __shfl_xor(Q[jb][g], 1, 64);       // every lane takes part
+                        v += (l15 & 1) ? qx : -qx;
+                        Q[jb][g] = 0.0;
+                    }
+                    P[jb][g] = 0.0;
+                    if (okr && 16 * jb + l15 < nj) atomic_add_f64(yp + 16 * jb, -v);
+                }
+            }
+        }
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        if (ch + 2 < nch) run_chunk(a0, ch, std::true_type{}); else run_chunk(a0, ch, std::false_type{});
+        if (ch + 1 < nch) {
+            if (ch + 3 < nch) run_chunk(a1, ch + 1, std::true_type{}); else run_chunk(a1, ch + 1, std::false_type{});
+        }
+    }
+    __syncthreads();                                              // the next segment overwrites Xs and rows_s
+    }
+}
+
+template <int E, int KB>
+__global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
+    const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
+    const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
+    int nrr, int j0)
+{
+    constexpr int NJ = 64 * E;            // real columns of Y per pass
+    constexpr int NJB = NJ / 16;
+    constexpr int RT = 64 / E;            // rows per tile step (the same bytes of L per step, real and complex)
+    constexpr int LDT = RT + 2;
+    constexpr int NQ = RT / 4;            // k-steps per tile
+    constexpr int NW = WIDE_THREADS / 64;
+    constexpr int JW = NJB / 2;           // j-blocks per wave
+    constexpr int NL = 64 * RT * E / WIDE_THREADS;   // doubles of an L block per thread (8)
+    constexpr int NY = NJ * RT / WIDE_THREADS;       // entries of the gathered rows of Y per thread (8)
+    __shared__ double Xt[2][NJ][LDT];     // Xt[.][j][r]
+    __shared__ double Lt[2][E][64][LDT];  // Lt[.][re/im][c][r]
+    __shared__ int32_t rows_s[WIDE_MAX_RUN * 64];   // rows of Y the run gathers
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nj = min(NJ, nrr - j0);
+    const int cb = w & 3, jh = w >> 2;    // this wave: columns 16 cb + [0, 16) of every block, j-blocks JW jh + [0, JW)
+    // the workgroup's share of the step: consecutive segments (runs of row tiles of one task) of the work list
+    for (int seg = wg_first[blockIdx.x]; seg < wg_first[blockIdx.x + 1]; seg++) {
+    const SolveRange e = work[seg];
+    const SolveGroupUpd t = tasks[e.task];
+    const int ncols = t.ncols;
+    const int row0 = e.tile0 * 64;
+    const int rows_run = min(64 * min(e.ntiles, WIDE_MAX_RUN), t.nrows - row0);
+    const int ntile = (rows_run + RT - 1) / RT;
+    v4d P[KB][JW], Q[E == 2 ? KB : 1][JW];
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) { P[b][jj] = (v4d){0.0, 0.0, 0.0, 0.0}; if constexpr (E == 2) Q[b][jj] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+    double lreg[2][NL], yreg[NY];
+    const double *__restrict__ Lbase = Lx + (t.a_off + row0) * E;
+    // block b of tile ti -> registers: real: lane = row, 8 columns per wave; complex: 32 rows x 2 column quads per wave.
+    // Rows past the end of the run meet zero rows of Xt, columns past the task are never flushed: both read clamped.
+    auto load_L = [&](double (&a)[NL], int ti, int b) {
+        if constexpr (E == 1) {
+            const int r = min(ti * RT + lane, rows_run - 1);
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                const int c = min(64 * b + 8 * w + i, ncols - 1);
+                a[i] = Lbase[r + (int64_t)c * t.lda];
+            }
+        } else {
+            const int r = min(ti * RT + (lane & 31), rows_run - 1);
+#pragma unroll
+            for (int i = 0; i < NL / 2; i++) {
+                const int c = min(64 * b + 4 * (2 * w + (lane >> 5)) + i, ncols - 1);
+                const double2 v = *reinterpret_cast<const double2 *>(Lbase + 2 * (r + (int64_t)c * t.lda));
+                a[2 * i] = v.x; a[2 * i + 1] = v.y;
+            }
+        }
+    };
+    auto store_L = [&](const double (&a)[NL], int buf) {
+        if constexpr (E == 1) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) Lt[buf][0][8 * w + i][lane] = a[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL / 2; i++) {
+                const int c = 4 * (2 * w + (lane >> 5)) + i;
+                Lt[buf][0][c][lane & 31] = a[2 * i];
+                Lt[buf][1][c][lane & 31] = a[2 * i + 1];
+            }
+        }
+    };
+    // gathered rows of Y of tile ti: unit u = w + NW i -> rows 4 (u / NJB) + lane/16, real columns 16 (u % NJB) + lane%16
+    auto load_Y = [&](int ti) {
+#pragma unroll
+        for (int i = 0; i < NY; i++) {
+            const int u = w + NW * i, j = 16 * (u % NJB) + l15, r = ti * RT + 4 * (u / NJB) + l4;
+            yreg[i] = Y[(int64_t)rows_s[min(r, rows_run - 1)] * ldr + j0 + min(j, nj - 1)];
+        }
+    };
+    // (the mask is applied here, not at the load: the wave would wait for the loads where they are issued)
+    auto store_Y = [&](int slot, int ti) {       // tile ti into buffer slot & 1
+#pragma unroll
+        for (int i = 0; i < NY; i++) {
+            const int u = w + NW * i, j = 16 * (u % NJB) + l15, r = ti * RT + 4 * (u / NJB) + l4;
+            Xt[slot & 1][j][4 * (u / NJB) + l4] = keep_if(yreg[i], r < rows_run && j < nj);
+        }
+    };
+    // the first two blocks of L are requested before the row list is staged (their latency runs under it)
+    load_L(lreg[0], 0, 0);
+    load_L(lreg[1], 0, 1);                                        // KB >= 2: phase 1 of tile 0 exists
+    for (int i = tid; i < rows_run; i += WIDE_THREADS) rows_s[i] = Ls[t.ls_off + row0 + i];
+    __syncthreads();
+    load_Y(0);
+    store_L(lreg[0], 0);
+    store_Y(0, 0);
+    __syncthreads();
+    for (int ti = 0; ti < ntile; ti++) {
+        // Every phase issues the same loads and stores whether or not a next tile or block exists (past the end they
+        // repeat the last tile / a clamped column and land in buffers nobody reads): with requests that are issued
+        // on some paths only, the compiler can no longer count how many younger ones may stay in flight and waits
+        // for all of them at every use.
+        const int tn = min(ti + 1, ntile - 1);
+#pragma unroll
+        for (int b = 0; b < KB; b++) {
+            // phase p = KB ti + b works on Lt[b & 1] (KB is even); block p + 1 is in lreg[(b + 1) & 1], block p + 2 is
+            // requested now into lreg[b & 1] (written to LDS at the end of the previous phase)
+            if (b == 0) load_Y(tn);
+            load_L(lreg[b & 1], min(ti + (b + 2) / KB, ntile - 1), (b + 2) % KB);
+            if (64 * b < ncols) {                                 // uniform; no memory requests inside
+                const double *__restrict__ la = &Lt[b & 1][0][16 * cb + l15][l4];
+                const double *__restrict__ xa = &Xt[ti & 1][16 * JW * jh + l15][l4];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double ar = la[4 * q];
+                    double ai = 0.0;
+                    if constexpr (E == 2) ai = la[64 * LDT + 4 * q];
+#pragma unroll
+                    for (int jj = 0; jj < JW; jj++) {
+                        const double y = xa[16 * jj * LDT + 4 * q];
+                        P[b][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, y, P[b][jj], 0, 0, 0);
+                        if constexpr (E == 2) Q[b][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, y, Q[b][jj], 0, 0, 0);
+                    }
+                }
+            }
+            store_L(lreg[(b + 1) & 1], (b + 1) & 1);
+            if (b == KB - 1) store_Y(ti + 1, tn);
+            __syncthreads();
+        }
+    }
+    // x1[c][j] -= sum: lane holds columns 64 b + 16 cb + lane/16 + 4g, real column 16 (JW jh + jj) + lane%16
+    double *__restrict__ x1 = Y + (int64_t)t.x0 * ldr + j0 + l15;
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int c = 64 * b + 16 * cb + l4 + 4 * g, jo = 16 * (JW * jh + jj);
+                double v = P[b][jj][g];
+                if constexpr (E == 2) {
+                    const double qx = __shfl_xor(Q[b][jj][g], 1, 64);        // every lane takes part
+                    v += (l15 & 1) ? -qx : qx;
+                }
+                if (c < ncols && jo + l15 < nj) atomic_add_f64(x1 + (int64_t)c * ldr + jo, -v);
+            }
+    __syncthreads();                                              // the next segment overwrites the LDS images
+    }
+}
+
 }  // namespace mi355

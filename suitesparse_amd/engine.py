@@ -43,6 +43,7 @@ EXPORTS = [
     "mi355_partition", "mi355_factor_partition", "mi355_factor_partition_info", "mi355_comm_create", "mi355_rccl_unique_id",
     "mi355_comm_create_rccl", "mi355_comm_adopt_rccl", "mi355_comm_free", "mi355_factor_numeric_multi",
     "mi355_super_solve_multi_dev", "mi355_factor_gather_multi", "mi355_factor_reduce_plan",
+    "mi355_factor_create_limited", "mi355_device_memory", "mi355_current_device",
 ]
 
 # mi355_transport (include/mi355_cholmod.h): blocking collectives of the caller's
@@ -77,6 +78,11 @@ def lib():
         L.mi355_last_error.restype = C.c_char_p
         L.mi355_factor_create.argtypes = [C.c_int, C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p,
                                           C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.mi355_factor_create_limited.argtypes = [C.c_int, C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p,
+                                                  C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_double,
+                                                  C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
+        L.mi355_device_memory.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mi355_current_device.argtypes = [C.POINTER(C.c_int)]
         L.mi355_factor_free.argtypes = [C.c_void_p]
         L.mi355_factor_set_matrix.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p]
         L.mi355_factor_set_matrix_zomplex.argtypes = [C.c_void_p, _i64p, _i64p, C.c_void_p, _f64p, _f64p]
@@ -255,11 +261,25 @@ STAT_KEYS = ["total_ms", "gemm_ms", "gemm_launches", "potrf_ms", "potrf_launches
              "flops_gemm128", "flops_gemm64", "tiles_gemm128", "tiles_gemm64", "flops_gemm128_here", "reduce_overlap_launches"]
 
 
+def device_memory(device=0):
+    """(total, free) bytes of a device (cholmod_l_gpu_memorysize, CHOLMOD/GPU/cholmod_gpu.c:63-131)"""
+    t, f = C.c_int64(0), C.c_int64(0)
+    _check(lib().mi355_device_memory(int(device), C.byref(t), C.byref(f)))
+    return int(t.value), int(f.value)
+
+
+def current_device():
+    d = C.c_int(0)
+    _check(lib().mi355_current_device(C.byref(d)))
+    return int(d.value)
+
+
 class SupernodalFactor:
     """Device-resident supernodal factor (cholmod_factor with is_super, CHOLMOD/Include/cholmod.h:1584-1651)."""
 
-    def __init__(self, sym, device=0, xtype=1):
-        """xtype: 1 = real L, 2 = complex L (cholmod.h:134-137)"""
+    def __init__(self, sym, device=0, xtype=1, max_bytes=0, max_fraction=0.0):
+        """xtype: 1 = real L, 2 = complex L (cholmod.h:134-137); max_bytes / max_fraction: cap on the device memory of the
+        handle (Common->maxGpuMemBytes / maxGpuMemFraction, mi355_factor_create_limited); self.needed_bytes = what it takes"""
         self.E = 2 if xtype == 2 else 1
         self.n = int(sym["n"])
         self.nsuper = int(sym["nsuper"])
@@ -276,9 +296,11 @@ class SupernodalFactor:
         def arr(a):
             a = np.ascontiguousarray(a, dtype=np.int64)
             return a if a.size else np.zeros(1, dtype=np.int64)
-        rc = lib().mi355_factor_create(xtype, self.n, self.nsuper, arr(sym["Super"]), arr(sym["Lpi"]),
-                                       arr(sym["Lpx"]), Ls, self.ssize, self.xsize, int(device),
-                                       C.byref(self._h))
+        need = C.c_int64(0)
+        rc = lib().mi355_factor_create_limited(xtype, self.n, self.nsuper, arr(sym["Super"]), arr(sym["Lpi"]),
+                                               arr(sym["Lpx"]), Ls, self.ssize, self.xsize, int(device),
+                                               int(max_bytes), float(max_fraction), C.byref(need), C.byref(self._h))
+        self.needed_bytes = int(need.value)
         _check(rc)
 
     def close(self):

@@ -514,10 +514,50 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 }
 inline hipError_t hipGetSymbolAddress(void **p, const void *symbol) { *p = const_cast<void *>(symbol); return hipSuccess; }
 enum { hipHostMallocDefault = 0 };
-inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-inline hipError_t hipFree(void *p) { (void)hipDeviceSynchronize(); std::free(p); return hipSuccess; }
+// Allocation-failure injection and leak accounting for the tests (the reference's Tcov suite fails every malloc in turn
+// through SuiteSparse_config's allocator hooks, CHOLMOD/Tcov/t_memory.c; this is the device-side counterpart):
+//   hipcpu_fail_alloc_at(k)  the k-th allocation from now on (k = 1: the next one; hipMalloc and hipHostMalloc count
+//                            alike) fails with hipErrorOutOfMemory; 0 switches the injection off
+//   hipcpu_alloc_calls()     allocations attempted since the last hipcpu_fail_alloc_at
+//   hipcpu_live_allocs()     device + pinned allocations that have not been freed
+//   hipcpu_set_free_memory(b) what hipMemGetInfo reports as free (total stays 288 GB); < 0: back to the default
+namespace hipcpu {
+inline std::atomic<long> alloc_fail_at{0}, alloc_calls{0}, alloc_live{0};
+inline std::atomic<long long> mem_free_override{-1};
+inline bool alloc_should_fail()
+{
+    const long k = ++alloc_calls, f = alloc_fail_at.load();
+    return f > 0 && k == f;
+}
+}  // namespace hipcpu
+extern "C" {
+__attribute__((visibility("default"), used)) inline void hipcpu_fail_alloc_at(long k) { hipcpu::alloc_calls = 0; hipcpu::alloc_fail_at = k; }
+__attribute__((visibility("default"), used)) inline long hipcpu_alloc_calls() { return hipcpu::alloc_calls.load(); }
+__attribute__((visibility("default"), used)) inline long hipcpu_live_allocs() { return hipcpu::alloc_live.load(); }
+__attribute__((visibility("default"), used)) inline void hipcpu_set_free_memory(long long b) { hipcpu::mem_free_override = b; }
+}
+inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned)
+{
+    *p = hipcpu::alloc_should_fail() ? nullptr : std::malloc(bytes ? bytes : 1);
+    if (*p) hipcpu::alloc_live++;
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipHostFree(void *p) { if (p) hipcpu::alloc_live--; std::free(p); return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t bytes)
+{
+    *p = hipcpu::alloc_should_fail() ? nullptr : std::malloc(bytes ? bytes : 1);
+    if (*p) hipcpu::alloc_live++;
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipFree(void *p) { (void)hipDeviceSynchronize(); if (p) hipcpu::alloc_live--; std::free(p); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b)
+{
+    *total_b = (size_t)288 << 30;
+    const long long o = hipcpu::mem_free_override.load();
+    *free_b = o >= 0 ? (size_t)o : *total_b - ((size_t)1 << 30);
+    return hipSuccess;
+}
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st)
 {

@@ -294,6 +294,15 @@ def test_every_solve_path_through_the_abi(engine, kind, size):
     t.test_every_solve_path_against_the_oracle(engine, kind, size)
 
 
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,wgs", [(False, 300, 100, 20, 256), (False, 130, 70, 70, 256), (True, 140, 50, 7, 256),
+                                                 (True, 70, 60, 70, 256), (False, 600, 130, 6, 3), (True, 300, 90, 5, 2)])
+def test_wide_multi_rhs_sweeps_through_the_abi(engine, cplx, n0, n1, nrhs, wgs):
+    """k_solve_fwd_wide / k_solve_bwd_wide (tuning key 23) from their own source on the CPU: contraction over a whole solve
+    group, real (256 columns) and complex (128), ragged blocks and row tiles, more than one pass over the right-hand sides"""
+    import test_gpu_parity as t
+    t.test_wide_multi_rhs_sweeps(engine, cplx, n0, n1, nrhs, wgs)
+
+
 @pytest.mark.parametrize("kind,n,seed,tiny_max", [("arrow", 150, 32, 0), ("sparse", 60, 35, 2048)])
 def test_random_structure_end_to_end_through_the_abi(engine, kind, n, seed, tiny_max):
     """random SPD structure under a random permutation, the way a CHOLMOD caller would use the library: our symbolic
@@ -451,3 +460,54 @@ def test_host_solve_through_the_lanes(engine):
         L.close()
     finally:
         engine.set_tuning(22, 4096); engine.set_tuning(21, 32); engine.set_tuning(20, 4)
+
+
+def test_solve_recovers_after_a_failed_allocation(engine):
+    """mi355_solve_x keeps its device images of B and X from call to call; an allocation that fails
+    while they grow must not leave the old capacity on record with the buffer gone -- the natural recovery, the same
+    solve with fewer right-hand sides, has to work.  Every allocation of a 40-column solve is failed in turn (the CPU
+    stand-in of the HIP runtime injects the failure); after each failure a 3-column solve must succeed and be right."""
+    import ctypes as C
+    emu = engine.lib()
+    emu.hipcpu_alloc_calls.restype = C.c_long
+    emu.hipcpu_live_allocs.restype = C.c_long
+    emu.hipcpu_fail_alloc_at.argtypes = [C.c_long]
+    g = load_golden("lap3d_8_metis")
+    n = g["n"]
+    rng = np.random.default_rng(5)
+    base_live = emu.hipcpu_live_allocs()
+    L = engine.SupernodalFactor(sym_of(g))
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    assert L.numeric(beta=g["beta"]) == 0
+    L.set_perm(g["Perm"])
+    Bs, Bl = rng.standard_normal((n, 3)), rng.standard_normal((n, 40))
+    Xs = L.solve(Bs, sys=0)             # (buffers for 3 columns now exist)
+    failed = 0
+    try:
+        for k in range(1, 40):
+            emu.hipcpu_fail_alloc_at(k)
+            try:
+                Xl = L.solve(Bl, sys=0)
+                injected = emu.hipcpu_alloc_calls() >= k
+            except engine.Mi355Error as e:
+                assert e.code == -2, e               # CHOLMOD_OUT_OF_MEMORY
+                injected, Xl = True, None
+                failed += 1
+            emu.hipcpu_fail_alloc_at(0)
+            assert relerr(L.solve(Bs, sys=0), Xs) < 1e-13, k        # the smaller solve works whatever happened before
+            if Xl is not None:
+                assert relerr(L.solve(Bl, sys=0), Xl) < 1e-13
+            if not injected:
+                break
+            # shrink back so that the next round has to grow the buffers again
+            L.close()
+            L = engine.SupernodalFactor(sym_of(g))
+            L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+            assert L.numeric(beta=g["beta"]) == 0
+            L.set_perm(g["Perm"])
+            assert relerr(L.solve(Bs, sys=0), Xs) < 1e-13
+    finally:
+        emu.hipcpu_fail_alloc_at(0)
+    assert failed >= 2
+    L.close()
+    assert emu.hipcpu_live_allocs() == base_live

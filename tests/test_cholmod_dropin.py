@@ -565,3 +565,129 @@ def test_full_size_dropin_factorize_and_solve():
     print(json.dumps(t))
     assert t["dropin_factorize_second_s"] < t["reference_cpu_factorize_second_s"]
     r.close(); u.close()
+
+
+# ---- soft fallback, memory limits, allocation failures (VERDICT r02 "missing" 4) ---------------------------------------
+
+def _factor_and_check(r, g, expect_device):
+    """analyze on the fixture's permutation, cholmod_l_factorize, cholmod_l_solve; the factor must be the fixture's
+    whoever computed it; returns the counters after the factorization"""
+    n = g["n"]
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    t0 = r.calls_taken()
+    c0 = r.counters()
+    assert r.factorize_full(beta=g["beta"]) == g["status"] == 0
+    t1 = r.calls_taken()
+    c = r.counters()
+    assert relerr(r.Lx(), g["Lx"]) < 1e-10
+    assert r.info()["minor"] == n
+    if expect_device is not None:
+        assert (t1[0] - t0[0] == 1) == expect_device, (t0, t1)
+        # the CPU worker zeroes its BLAS counters when it starts (t_cholmod_super_numeric_worker.c:246-266) and counts its
+        # calls; a device run leaves them as they were
+        if expect_device:
+            assert c["cpu_blas_calls"] == c0["cpu_blas_calls"] and c["cpu_blas_time"] == c0["cpu_blas_time"], (c0, c)
+        else:
+            assert c["cpu_blas_calls"] > 0 and c["cpu_blas_time"] != c0["cpu_blas_time"], (c0, c)
+        assert c["L_useGPU"] == (1 if expect_device else 0), c
+    A = _dense_A(g) + g["beta"] * np.eye(n)
+    X = r.solve(g["B"])
+    assert relerr(X, np.linalg.solve(A, g["B"])) < 1e-9
+    return c
+
+
+@pytest.mark.parametrize("which", BOTH)
+@pytest.mark.parametrize("name", ["lap2d_16_metis", "demo_bcsstk01", "helm3d_6_metis"])
+def test_soft_fallback_when_the_factor_exceeds_the_memory_limit(which, name):
+    """Common->maxGpuMemBytes / maxGpuMemFraction (CHOLMOD/GPU/cholmod_gpu.c:446-489) cap what a device image may take; a
+    factor that needs more is factorized by the unchanged CPU worker -- silently, status CHOLMOD_OK, L->useGPU = 0 -- as
+    the reference does when gpu_init cannot set itself up (t_cholmod_super_numeric_worker.c:233-244).  lap2d_16 and
+    helm3d_6 are lower-stored with a permutation: cholmod_factorize_p hands A itself over (deferred permutation), so the
+    fallback first builds S = tril (P A P') the way cholmod_factorize_p would have."""
+    g = load_golden(name)
+    r = _cholmod(which)
+    base = r.live_handles()
+    f0, _ = r.fallbacks()
+    r.set_gpu_mem(max_bytes=4096)                        # nothing fits into 4 KB
+    _factor_and_check(r, g, expect_device=False)
+    f1, why = r.fallbacks()
+    assert f1 == f0 + 1 and "device memory" in why, (f0, f1, why)
+    assert r.live_handles() == base
+    # a fraction works the same way
+    r.set_gpu_mem(max_fraction=1e-9)
+    _factor_and_check(r, g, expect_device=False)
+    assert r.fallbacks()[0] == f1 + 1
+    # the limit lifted: the next analysis asks for the device again and gets it
+    r.set_gpu_mem(0, 0.0)
+    _factor_and_check(r, g, expect_device=True)
+    assert r.fallbacks()[0] == f1 + 1
+    assert r.live_handles() == base + 1
+    r.close()
+    assert r.L.ref_live_handles() == base
+
+
+@pytest.mark.parametrize("which", BOTH)
+def test_memory_knobs_from_the_environment(which, monkeypatch):
+    """Common->useGPU = EMPTY: CHOLMOD_USE_GPU decides, and CHOLMOD_GPU_MEM_BYTES / CHOLMOD_GPU_MEM_FRACTION set
+    Common->maxGpuMemBytes / maxGpuMemFraction (fraction clamped to [0, 1]) -- cholmod_super_symbolic.c:250-289"""
+    g = load_golden("demo_bcsstk02")
+    r = _cholmod(which)
+    r.set_use_gpu(-1)
+    monkeypatch.setenv("CHOLMOD_USE_GPU", "1")
+    monkeypatch.setenv("CHOLMOD_GPU_MEM_BYTES", "123456789")
+    monkeypatch.setenv("CHOLMOD_GPU_MEM_FRACTION", "7.5")
+    r.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.counters()["useGPU"] == 1
+    assert r.gpu_mem() == (123456789.0, 1.0)
+    assert r.factorize_full() == 0                       # 123 MB are plenty for bcsstk02
+    assert r.counters()["cpu_blas_calls"] == 0
+    r.close()
+    # CHOLMOD_USE_GPU=0: the limits are not even read
+    r = _cholmod(which)
+    r.set_use_gpu(-1)
+    monkeypatch.setenv("CHOLMOD_USE_GPU", "0")
+    monkeypatch.setenv("CHOLMOD_GPU_MEM_BYTES", "5")
+    r.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.counters()["useGPU"] == 0 and r.gpu_mem()[0] == 0.0
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["demo_bcsstk02", "lap2d_16_metis"])
+def test_every_allocation_failure_falls_back_to_the_cpu(name):
+    """the reference's Tcov suite fails every malloc in turn (CHOLMOD/Tcov/t_memory.c, t_raw_factor.c:343-347); here the
+    k-th device / pinned allocation of analyze -> factorize -> solve fails, for every k until a run needs fewer than k:
+    each run must still return the reference's factor and solution (the CPU workers take over what the device could not
+    do), leave no device image behind when the numeric phase fell back, and leak nothing.  CPU build of the engine only:
+    its stand-in for the HIP runtime carries the injection (tests/helpers/hipcpu/hip/hip_runtime.h)."""
+    import ctypes as C
+    g = load_golden(name)
+    r = _cholmod("cpu")
+    emu = C.CDLL(CPUEMU)
+    emu.hipcpu_alloc_calls.restype = C.c_long
+    emu.hipcpu_live_allocs.restype = C.c_long
+    emu.hipcpu_fail_alloc_at.argtypes = [C.c_long]
+    r.close()
+    base_handles = _cholmod("cpu").L.ref_live_handles()
+    base_live = emu.hipcpu_live_allocs()
+    k, ran_clean, fell_back = 1, False, 0
+    try:
+        while not ran_clean:
+            assert k < 400, "allocation count does not converge"
+            r = _cholmod("cpu")
+            f0 = r.fallbacks()[0]
+            emu.hipcpu_fail_alloc_at(k)
+            _factor_and_check(r, g, expect_device=None)
+            used = emu.hipcpu_alloc_calls()
+            emu.hipcpu_fail_alloc_at(0)
+            ran_clean = used < k                        # the run made fewer than k allocations: nothing was injected
+            fell_back += r.fallbacks()[0] - f0
+            r.close()
+            assert r.L.ref_live_handles() == base_handles, k
+            assert emu.hipcpu_live_allocs() == base_live, (k, emu.hipcpu_live_allocs(), base_live)
+            k += 1
+    finally:
+        emu.hipcpu_fail_alloc_at(0)
+    assert k > 10 and fell_back >= k - 2, (k, fell_back)     # every injected failure ended in a fallback, none in an error

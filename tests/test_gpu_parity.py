@@ -730,6 +730,55 @@ def test_every_solve_path_against_the_oracle(engine, kind, size):
         engine.set_tuning(9, 5); engine.set_tuning(10, 1)
 
 
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,wgs", [(False, 300, 200, 20, 256), (False, 600, 150, 70, 256), (False, 100, 330, 5, 256),
+                                                 (True, 300, 90, 7, 256), (True, 130, 200, 40, 256), (True, 70, 100, 70, 256),
+                                                 (False, 600, 150, 70, 3), (True, 300, 90, 7, 2), (False, 1500, 400, 9, 5)])
+def test_wide_multi_rhs_sweeps(engine, cplx, n0, n1, nrhs, wgs):
+    """the wide sweeps (tuning key 23; k_solve_fwd_wide / k_solve_bwd_wide): the rows below a solve group of more than
+    64 columns take all its columns in one pass -- contraction depth 256 real / 128 complex, ragged last block and last
+    row tile, several passes over the right-hand sides (more than 64 real, more than 64 complex) -- on a hand-built
+    two-supernode structure whose first supernode has n0 columns and scattered rows of the second: against the
+    oracle's sweeps, and against the per-block kernels (key 23 off) on the same factor.  wgs (key 24): workgroups the tiles
+    of a step are dealt to -- few of them give shares of several segments that run over task boundaries"""
+    from oracle import port
+    engine.set_tuning(24, wgs)
+    n = n0 + n1
+    extra = np.array(sorted(set(range(n0, n, 3)) | set(range(n0 + 1, n, 7)) | {n - 1}), dtype=np.int64)
+    rows0 = np.concatenate([np.arange(n0), extra])
+    rows1 = np.arange(n0, n)
+    sym = dict(n=n, nsuper=2, Super=np.array([0, n0, n]), Lpi=np.array([0, len(rows0), len(rows0) + n1]),
+               Lpx=np.array([0, len(rows0) * n0, len(rows0) * n0 + n1 * n1]), Ls=np.concatenate([rows0, rows1]))
+    sym["ssize"] = len(sym["Ls"])
+    sym["xsize"] = int(sym["Lpx"][-1])
+    sym["maxcsize"] = len(extra) ** 2
+    rng = np.random.default_rng(n0 + nrhs)
+    rnd = (lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) if cplx else (lambda *sh: rng.standard_normal(sh))
+    A = np.zeros((n, n), dtype=np.complex128 if cplx else np.float64)
+    A[np.ix_(rows0, np.arange(n0))] = rnd(len(rows0), n0)
+    A[n0:, n0:] = rnd(n1, n1)
+    A = np.tril(A, -1)
+    A = A + A.conj().T
+    A += np.eye(n) * (np.abs(A).sum(1).max() + 1)
+    import scipy.sparse as sp
+    S = sp.csc_matrix(np.tril(A))
+    S.sort_indices()
+    Sp, Si, Sx = S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data
+    L = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+    assert L.super_numeric(Sp, Si, Sx) == 0
+    so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx)
+    assert so == 0
+    B = rnd(n, nrhs)
+    Yo = port.super_solve(sym, Lo, B, lower=True)
+    Xo = port.super_solve(sym, Lo, Yo, lower=False)
+    try:
+        for wide in (1, 0):
+            engine.set_tuning(23, wide)
+            assert relerr(L.super_lsolve(B), Yo) < 1e-10, wide
+            assert relerr(L.super_ltsolve(Yo), Xo) < 1e-10, wide
+    finally:
+        engine.set_tuning(23, 1); engine.set_tuning(24, 256)
+
+
 @pytest.mark.parametrize("kind,size,nrhs", [("lap3d", 20, 8), ("lap3d", 20, 23), ("lap2d", 90, 64), ("elast", 8, 70),
                                             ("lap3d", 28, 130)])
 def test_multi_rhs_solve_on_mfma(engine, kind, size, nrhs, have_ref):

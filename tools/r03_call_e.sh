@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 3, GPU call F: wide sweeps after the branch-free rewrite -- parity, nrhs = 64 times at 150^3 and config 5, kernel trace
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O
+cd $R
+( while true; do sleep 45; echo "[hb] $(date +%T)"; done ) & HB=$!
+trap "kill $HB 2>/dev/null" EXIT
+timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 300 --timeout-method thread -k "wide_multi or every_solve_path or multi_rhs_solve or complex_hermitian or solve_with_permutation" > $O/parity.log 2>&1 || { tail -40 $O/parity.log; exit 1; }
+tail -3 $O/parity.log
+for w in 256; do
+timeout -k 10 400 python -u bench.py --grid 150 --steps 1 --warmup 0 --no-cpu --solve --nrhs 64 --tune 24=$w > $O/solve64_lap3d150_wgs$w.json 2> $O/err.txt || { tail -20 $O/err.txt; exit 1; }
+python3 -c "import json,sys; print('lap3d150 wgs=$w', json.load(open('$O/solve64_lap3d150_wgs$w.json'))['config']['solve'])"
+timeout -k 10 400 python -u bench.py --problem helm --steps 1 --warmup 0 --no-cpu --solve --nrhs 64 --tune 24=$w > $O/solve64_helm100_wgs$w.json 2> $O/err.txt || { tail -20 $O/err.txt; exit 1; }
+python3 -c "import json,sys; print('helm100 wgs=$w', json.load(open('$O/solve64_helm100_wgs$w.json'))['config']['solve'])"
+done
+bash tools/solve_profile.sh 64 > $O/solve_kernels_nrhs64.txt 2> $O/prof.err || { tail $O/prof.err; exit 1; }
+grep -A6 "wide" $O/solve_kernels_nrhs64.txt | cut -c1-150
