@@ -148,9 +148,11 @@ def main():
     if world > 1:
         dist.init_process_group(os.environ.get("MI355_BENCH_BACKEND", "nccl"))
     from suitesparse_amd import engine
+    tune_now = {}
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         engine.set_tuning(int(k), int(v))
+        tune_now[int(k)] = int(v)
 
     default_grid = {"lap3d": 150, "lap2d": 2000, "elast": 80, "helm": 100}[args.problem]
     grid = args.grid or default_grid
@@ -167,16 +169,25 @@ def main():
         # the whole N > 1 driver runs behind the C ABI (mi355_factor_numeric_multi) on an RCCL communicator of the
         # engine's own; MI355_MULTI=python keeps the older torch.distributed driver of multigpu.py.  Whether the
         # communicator could be created is agreed on by all ranks, so that they take the same path.
+        # MI355_MULTI=python (explicit request only) keeps the older torch.distributed driver of multigpu.py.  There is NO
+        # silent fallback: a rank that cannot create the engine's communicator makes every rank stop with an error, so
+        # that a scaling number is never a number of the other algorithm.
         comm = None
-        if os.environ.get("MI355_MULTI", "c") != "python" and dist.get_backend() == "nccl":
+        if os.environ.get("MI355_MULTI", "c") != "python":
+            if dist.get_backend() != "nccl":
+                raise SystemExit("bench.py --gpus N runs the C driver on RCCL (backend nccl); for the torch.distributed "
+                                 "rehearsal on another backend set MI355_MULTI=python")
+            err = ""
             try:
                 comm = engine.Comm.from_torch_distributed(local_rank)
             except Exception as e:      # noqa: BLE001
-                print(f"[rank {rank}] RCCL communicator of the engine not created: {e}", file=sys.stderr, flush=True)
+                err = f"[rank {rank}] RCCL communicator of the engine not created: {e}"
+                print(err, file=sys.stderr, flush=True)
             ok = torch.tensor([1 if comm is not None else 0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
-                comm = None
+                dist.destroy_process_group()
+                raise SystemExit(err or f"[rank {rank}] another rank could not create the engine's RCCL communicator")
         if comm is not None:
             runner = multigpu.PartitionedFactor(L, sym, rank, world, comm=comm)
         else:
@@ -242,7 +253,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
         # (FETCH_SIZE x2 on gfx950, WRITE_SIZE; tools/pmc_traffic.py), when one exists
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.problem}{grid}.json")
-        if world == 1 and os.path.exists(pmc):
+        if world == 1 and args.ordering == "nd" and os.path.exists(pmc):
             try:
                 t = json.load(open(pmc))
                 key = [k for k in t if "k_gemm128" in k][0]
@@ -264,7 +275,12 @@ def main():
                    f"subtree-to-GPU x{world} + " + ("owner-computes top (1024-column blocks, broadcasts)"
                                                     if runner.dist else "replicated top") +
                    (", C driver on the engine's RCCL communicator" if runner.comm is not None
-                    else ", torch.distributed driver"),
+                    else ", torch.distributed driver (MI355_MULTI=python)"),
+                   "multi_driver": None if world == 1 else
+                   {"driver": "C (mi355_factor_numeric_multi)" if runner.comm is not None else "python (torch.distributed)",
+                    "tuning": {"16_dist_lookahead": tune_now.get(16, 1), "17_dist_pieces": tune_now.get(17, 1),
+                               "19_reduce_channel": tune_now.get(19, 0)},
+                    "validated_on": "CPU stand-in for RCCL and gloo only (N > 1 has not run on xGMI before this line)"},
                    "analyze_s": round(t_analyze, 2), "setup_s": round(t_setup, 2),
                    "frac_fp64_mfma_peak": round(gflops * 1e-3 * (4 if cplx else 1)
                                                 / (FP64_MFMA_PEAK_TFLOPS * world), 4),

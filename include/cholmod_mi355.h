@@ -76,6 +76,17 @@ void cholmod_mi355_calls_taken (int64_t out [4]) ;
  * since the library was loaded; reason (may be NULL): the engine's message of the last time. */
 int64_t cholmod_mi355_fallbacks (char *reason, size_t len) ;
 
+/* N ranks (no counterpart in the reference, which knows one device: CHOLMOD/GPU/cholmod_gpu.c:138-142).  The application
+ * runs one process or thread per GPU, each with its own cholmod_common, the same matrix and the same analysis, and
+ * registers its rank's engine communicator (a mi355_comm* from mi355_comm_create_rccl, mi355_comm_adopt_rccl or
+ * mi355_comm_create, include/mi355_cholmod.h) for its Common.  From then on cholmod_l_factorize with that Common runs
+ * mi355_factor_partition (once per factor) + mi355_factor_numeric_multi + mi355_factor_gather_multi: disjoint subtrees on
+ * the ranks, the top supernodes distributed, and every rank's L->x = the complete factor.  Every rank must make the same
+ * CHOLMOD calls in the same order; a device failure is CHOLMOD_GPU_PROBLEM on the rank that has it (no soft fallback:
+ * the other ranks wait in their collectives).  cholmod_l_solve afterwards runs on each rank's host copy of L.
+ * comm == NULL removes the registration.  Returns TRUE / FALSE (bad arguments, out of memory). */
+int cholmod_mi355_register_comm (cholmod_common *Common, void *comm, int rank, int world) ;
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,7 +428,9 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * mi355_solve_x move through the lanes (default 4096; smaller ones take one plain copy); key 23: the wide multi-RHS
  * sweeps (default 1: the rows below a solve group of more than 64 columns take all its columns in one pass -- contraction
  * depth 256, 128 for a complex factor -- instead of one pass per 64-column block; 0: per-block kernels everywhere); key 24:
- * workgroups aimed at per launch of the wide kernels (default 256 = one per CU; read when a handle builds its solve lists); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * workgroups the tiles of a step are dealt to for the wide kernels (default 256 = one per CU; read when a handle builds its
+ * solve lists); key 25: 1 = the forward wide kernel of a real factor with 16 waves per workgroup on long shares (measured
+ * 3 % slower at 150^3, default 0); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -477,10 +477,13 @@ int ref_live_handles (void) { return cholmod_mi355_live_handles ( ) ; }
 void ref_calls_taken (int64_t *out) { cholmod_mi355_calls_taken (out) ; }
 void cholmod_mi355_forget (cholmod_factor *L) ;
 void ref_forget (void *hv) { cholmod_mi355_forget (((ref_ctx *) hv)->L) ; }
+int cholmod_mi355_register_comm (cholmod_common *Common, void *comm, int rank, int world) ;
+int ref_register_comm (void *hv, void *comm, int rank, int world) { return cholmod_mi355_register_comm (&((ref_ctx *) hv)->cm, comm, rank, world) ; }
 int64_t cholmod_mi355_fallbacks (char *reason, size_t len) ;
 int64_t ref_fallbacks (char *reason, int64_t len) { return cholmod_mi355_fallbacks (reason, (size_t) len) ; }
 #else
 int64_t ref_fallbacks (char *reason, int64_t len) { if (reason && len > 0) reason [0] = 0 ; return -1 ; }
+int ref_register_comm (void *hv, void *comm, int rank, int world) { (void) hv ; (void) comm ; (void) rank ; (void) world ; return 0 ; }
 void ref_forget (void *hv) { (void) hv ; }
 int ref_live_handles (void) { return -1 ; }
 void ref_calls_taken (int64_t *out) { out [0] = out [1] = out [2] = out [3] = -1 ; }

@@ -88,6 +88,7 @@ def _prototypes(L):
     L.ref_set_use_gpu.argtypes = [C.c_void_p, C.c_int]
     L.ref_set_gpu_mem.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.ref_get_gpu_mem.argtypes = [C.c_void_p, f64p]
+    L.ref_register_comm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.ref_fallbacks.argtypes = [C.c_char_p, C.c_int64]
     L.ref_fallbacks.restype = C.c_int64
     L.ref_counters.argtypes = [C.c_void_p, f64p]
@@ -137,6 +138,10 @@ class RefCholmod:
         out = np.zeros(2)
         self.L.ref_get_gpu_mem(self.h, out)
         return float(out[0]), float(out[1])
+
+    def register_comm(self, comm, rank, world):
+        """cholmod_mi355_register_comm: comm = the mi355_comm* of this rank (engine.Comm._h), None to remove it"""
+        return int(self.L.ref_register_comm(self.h, comm, int(rank), int(world)))
 
     def fallbacks(self):
         """(count, reason of the last one) of the drop-in's soft fallbacks to the CPU worker"""

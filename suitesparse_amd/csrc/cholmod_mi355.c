@@ -44,6 +44,7 @@ typedef struct
     size_t n, nsuper, ssize, xsize ;
     int lx ;                        // MI355_REAL / MI355_COMPLEX
     int perm_set ;                  // L->Perm is on the device (cholmod_mi355_solve2)
+    int multi_world ;               // > 1: the handle is partitioned over that many ranks (cholmod_mi355_register_comm)
 } entry_t ;
 
 static entry_t *table = NULL ;
@@ -104,8 +105,75 @@ static int remember_handle (const cholmod_factor *L, mi355_factor *h, int lx)
     e->L = L ; e->h = h ; e->super = L->super ; e->s = L->s ;
     e->n = L->n ; e->nsuper = L->nsuper ; e->ssize = L->ssize ; e->xsize = L->xsize ; e->lx = lx ;
     e->perm_set = 0 ;
+    e->multi_world = 0 ;
     pthread_mutex_unlock (&table_lock) ;
     return (1) ;
+}
+
+// multi_world of L's entry: set (world > 0) or read (world == 0)
+static int multi_flag (const cholmod_factor *L, int world)
+{
+    int was = 0 ;
+    pthread_mutex_lock (&table_lock) ;
+    int k = find_locked (L) ;
+    if (k >= 0)
+    {
+        was = table [k].multi_world ;
+        if (world > 0) table [k].multi_world = world ;
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (was) ;
+}
+
+// ---- N ranks ------------------------------------------------------------------------------------------------------
+// One process (or thread) per GPU, each with its own cholmod_common, the same matrix and the same analysis.  The
+// application registers its rank's engine communicator (mi355_comm_create_rccl / _adopt_rccl / mi355_comm_create) for
+// its Common; cholmod_l_factorize then runs the subtree-to-GPU factorization behind mi355_factor_numeric_multi and
+// gathers the factor, so that every rank's L->x is the complete factor cholmod_factorize promises.  No counterpart in
+// the reference (one device only, CHOLMOD/GPU/cholmod_gpu.c:138-142).
+typedef struct { const cholmod_common *cm ; mi355_comm *comm ; int rank, world ; } comm_entry_t ;
+static comm_entry_t *comms = NULL ;
+static int comms_len = 0, comms_cap = 0 ;
+
+int cholmod_mi355_register_comm (cholmod_common *Common, void *comm, int rank, int world)
+{
+    if (!Common || (comm && (world < 1 || rank < 0 || rank >= world))) return (FALSE) ;
+    int ok = TRUE ;
+    pthread_mutex_lock (&table_lock) ;
+    int k ;
+    for (k = 0 ; k < comms_len ; k++) if (comms [k].cm == Common) break ;
+    if (!comm)
+    {
+        if (k < comms_len) comms [k] = comms [--comms_len] ;
+    }
+    else
+    {
+        if (k == comms_len && comms_len == comms_cap)
+        {
+            int cap = comms_cap ? 2 * comms_cap : 4 ;
+            comm_entry_t *t = realloc (comms, (size_t) cap * sizeof (comm_entry_t)) ;
+            if (t) { comms = t ; comms_cap = cap ; } else ok = FALSE ;
+        }
+        if (ok)
+        {
+            if (k == comms_len) comms_len++ ;
+            comms [k].cm = Common ; comms [k].comm = (mi355_comm *) comm ; comms [k].rank = rank ; comms [k].world = world ;
+        }
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (ok) ;
+}
+
+static mi355_comm *comm_of (const cholmod_common *Common, int *rank, int *world)
+{
+    mi355_comm *c = NULL ;
+    pthread_mutex_lock (&table_lock) ;
+    for (int k = 0 ; k < comms_len ; k++)
+    {
+        if (comms [k].cm == Common) { c = comms [k].comm ; *rank = comms [k].rank ; *world = comms [k].world ; break ; }
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (c) ;
 }
 
 static int perm_flag (const cholmod_factor *L, int set)
@@ -298,6 +366,9 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
     }
     // L is complex for a complex or zomplex A (cholmod_super_numeric.c:223-225)
     const int lx = (A->xtype == CHOLMOD_REAL) ? MI355_REAL : MI355_COMPLEX ;
+    int rank = 0, world = 1 ;
+    mi355_comm *comm = comm_of (Common, &rank, &world) ;
+    if (comm != NULL && world <= 1) comm = NULL ;
     mi355_factor *h = handle_of (L, lx) ;
     int rc = MI355_OK ;
     if (h == NULL)
@@ -357,15 +428,37 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
                     (const double *) A->x) ;
         }
         // only beta [0] is used (t_cholmod_super_numeric_worker.c:510-520)
+        if (rc == MI355_OK && comm != NULL)
+        {
+            // N ranks: subtrees to GPUs, the top distributed, then every rank receives the other ranks' columns and
+            // copies the complete factor to its L->x
+            if (multi_flag (L, 0) != world)
+            {
+                rc = mi355_factor_partition (h, rank, world, 2, 1) ;
+                if (rc == MI355_OK) (void) multi_flag (L, world) ;
+            }
+            if (rc == MI355_OK) rc = mi355_factor_numeric_multi (h, comm, beta [0], Common->quick_return_if_not_posdef,
+                    &minor, &status) ;
+            if (rc == MI355_OK && status == MI355_STATUS_OK) rc = mi355_factor_gather_multi (h, comm) ;
+            if (rc == MI355_OK) rc = mi355_factor_get_Lx (h, (double *) L->x) ;
+        }
         // L->x on the host is part of the contract (cholmod_solve, change_factor, rcond, factor_to_sparse and the user
         // read it): it is filled chunk by chunk WHILE the factorization runs, the bottom of the tree first
-        if (rc == MI355_OK) rc = mi355_factor_numeric_host (h, beta [0], Common->quick_return_if_not_posdef,
+        else if (rc == MI355_OK) rc = mi355_factor_numeric_host (h, beta [0], Common->quick_return_if_not_posdef,
                 (double *) L->x, &minor, &status) ;
     }
     if (rc == MI355_INVALID)
     {
         // the arrays of A or L are not what the wrapper's checks promised: nothing a CPU run would cure
         cholmod_l_error (CHOLMOD_INVALID, __FILE__, __LINE__, mi355_last_error ( ), Common) ;
+        cholmod_mi355_forget (L) ;
+        *ok = FALSE ;
+        return (TRUE) ;
+    }
+    if (rc != MI355_OK && comm != NULL)
+    {
+        // N ranks: a rank that left for its CPU worker would leave the others waiting in their collectives
+        gpu_problem (Common, __FILE__, __LINE__) ;
         cholmod_mi355_forget (L) ;
         *ok = FALSE ;
         return (TRUE) ;
@@ -417,7 +510,7 @@ int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, c
     if (L->xtype != CHOLMOD_REAL && L->xtype != CHOLMOD_COMPLEX) return (FALSE) ;
     if (L->minor < L->n) return (FALSE) ;           // not positive definite: the CPU worker sweeps what is in L->x
     mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
-    if (h == NULL) return (FALSE) ;
+    if (h == NULL || multi_flag (L, 0) > 1) return (FALSE) ;     // (N ranks: every rank solves on its complete L->x)
     const int rc = lower ? mi355_super_lsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d)
                          : mi355_super_ltsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d) ;
     if (rc == MI355_INVALID)
@@ -449,7 +542,7 @@ int cholmod_mi355_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_
     if (L->minor < L->n) return (FALSE) ;
     if (X->nrow != L->n || X->ncol != B->ncol || X->d < L->n) return (FALSE) ;
     mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
-    if (h == NULL) return (FALSE) ;
+    if (h == NULL || multi_flag (L, 0) > 1) return (FALSE) ;
     int rc = MI355_OK ;
     if (!perm_flag (L, 0))
     {

@@ -1616,10 +1616,14 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             if (st.gcount <= 0) continue;
             if (st.gcount > 0x7fffffffLL || st.stiles > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve tiles in one step");
             auto group_kernel = [&]() {
-                const dim3 g((unsigned)st.gcount, (unsigned)((nrr + SG_CW - 1) / SG_CW)), b(256);
+                // a step of one-block groups only (the leaf levels: 10^5 groups of a few columns) takes 64 real columns of Y per
+                // workgroup instead of 16: a quarter of the workgroups, each with four times the products of its one step
+                const int cw = (st.maxblk <= 1 && st.gcount >= 1024) ? 64 : SG_CW;
+                const dim3 g((unsigned)st.gcount, (unsigned)((nrr + cw - 1) / cw)), b(256);
                 const SolveGroupTask *gp = DS.sgroups.p + st.gfirst;
 #define MI355_SGM(T, EE, MB) hipLaunchKernelGGL((k_solve_group_mma<T, EE, MB>), g, b, 0, F->stream, gp, F->Dinv.p, F->Lx.p, X, d, nrr)
-#define MI355_SGM_MB(T, EE) do { if (st.maxblk <= 1) MI355_SGM(T, EE, 1); else if (st.maxblk <= 2) MI355_SGM(T, EE, 2); \
+#define MI355_SGM_MB(T, EE) do { if (cw == 64) hipLaunchKernelGGL((k_solve_group_mma<T, EE, 1, 64>), g, b, 0, F->stream, gp, F->Dinv.p, F->Lx.p, X, d, nrr); \
+                                 else if (st.maxblk <= 1) MI355_SGM(T, EE, 1); else if (st.maxblk <= 2) MI355_SGM(T, EE, 2); \
                                  else MI355_SGM(T, EE, SOLVE_GROUP); } while (0)
                 if (lower) { if (cplx) MI355_SGM_MB(false, 2); else MI355_SGM_MB(false, 1); }
                 else       { if (cplx) MI355_SGM_MB(true, 2); else MI355_SGM_MB(true, 1); }
@@ -1650,6 +1654,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, ptiles / std::max(1, tuning().solve_fwd_div_mma)));
             const unsigned grid = (unsigned)((ptiles + group - 1) / group);
             const int wnj = 64 * F->E;                  // real columns of Y per pass of the wide kernels
+            int64_t wt64 = 0;                           // 64-row tiles of the step's wide tasks
+            if (wide) for (int64_t u = 0; u < st.wcount; u++) wt64 += (DS.ssched.wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
             if (wide && st.wrcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
             if (lower) {
                 group_kernel();
@@ -1659,12 +1665,17 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                                            ptasks, ptmap, ptiles, group, F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 if (wide && st.wrcount > 0)
                     for (int j0 = 0; j0 < nrr; j0 += wnj) {
-#define MI355_WIDE(K) hipLaunchKernelGGL(K, dim3((unsigned)st.wgcount), dim3(WIDE_THREADS), 0, F->stream, \
+#define MI355_WIDE_T(K, NT) hipLaunchKernelGGL(K, dim3((unsigned)st.wgcount), dim3(NT), 0, F->stream, \
                                          DS.swtasks.p + st.wfirst, DS.swranges.p + st.wrfirst, DS.swwg.p + st.wgfirst, \
                                          F->Lx.p, F->dLs.p, X, d, nrr, j0)
-                        if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2>));
-                        else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2>));
-                        else MI355_WIDE((k_solve_fwd_wide<1, 4>));
+#define MI355_WIDE(K) MI355_WIDE_T(K, WIDE_THREADS)
+                        // real factor: 16 waves per workgroup (4 per SIMD: the kernel fits 128 registers) once the shares are
+                        // long enough to give every wave a slab (tuning key 25)
+                        const bool big = tuning().solve_wide_1024 && st.wgcount > 0 && wt64 >= 4 * st.wgcount;
+                        if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2, WIDE_THREADS>));
+                        else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2, WIDE_THREADS>));
+                        else if (big) MI355_WIDE_T((k_solve_fwd_wide<1, 4, 1024>), 1024);
+                        else MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS>));
                     }
             } else {
                 const int64_t prcount = wide ? st.nrmcount : st.rmcount;
@@ -1675,6 +1686,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                         else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_bwd_wide<1, 2>));
                         else MI355_WIDE((k_solve_bwd_wide<1, 4>));
 #undef MI355_WIDE
+#undef MI355_WIDE_T
                     }
                 if (prcount > 0) {
                     if (prcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
@@ -2091,6 +2103,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 22) tuning().host_staged_min_kb = std::max(0, value);
     else if (key == 23) tuning().solve_wide = value ? 1 : 0;
     else if (key == 24) tuning().solve_wide_wgs = std::max(1, value);
+    else if (key == 25) tuning().solve_wide_1024 = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -861,14 +861,14 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
 // Im(block) against the pair-swapped image of Y, as in k_solve_fwd_mma / k_solve_bwd_mma.
 //------------------------------------------------------------------------------
 constexpr int SG_CW = 16;      // real columns of Y per workgroup of k_solve_group_mma
-template <bool TRANS, int E, int MAXBLK>
+template <bool TRANS, int E, int MAXBLK, int CW = SG_CW>
 __global__ __launch_bounds__(256) void k_solve_group_mma(
     const SolveGroupTask *__restrict__ groups, const double *__restrict__ Dinv, const double *__restrict__ Lx,
     double *__restrict__ Y, int64_t ldr, int nrhs)
 {
     constexpr int NS = MAXBLK * (MAXBLK + 1) / 2;
     constexpr int NSETS = (E == 1) ? (NS < 8 ? NS : 8) : (NS < 4 ? NS : 4);
-    __shared__ double Yg[MAXBLK * NB][SG_CW + 2];
+    __shared__ double Yg[MAXBLK * NB][CW + 2];
     const SolveGroupTask t = groups[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int ncols = t.ncols, nblk = (ncols + NB - 1) / NB;
@@ -896,20 +896,20 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
         }
     };
     {
-        // blockIdx.y: which SG_CW real columns of Y this workgroup sweeps (a group's chain is MFMA-bound on one
+        // blockIdx.y: which CW real columns of Y this workgroup sweeps (a group's chain is MFMA-bound on one
         // CU -- 10 steps x 64 x 64 x nrhs -- so the right-hand sides are spread over workgroups)
-        const int j0 = blockIdx.y * SG_CW;
-        const int nj = min(SG_CW, nrhs - j0);
+        const int j0 = blockIdx.y * CW;
+        const int nj = min(CW, nrhs - j0);
         double m[NSETS][16 * E];
 #pragma unroll
         for (int u = 0; u < NSETS; u++) {
             const int s = TRANS ? NS - 1 - u : u;
             if (sg_c(s) < nblk) load(sg_b(s), sg_c(s), m[u]);
         }
-        // rows of Y the group owns -> LDS (thread: column tid % SG_CW, rows tid / SG_CW + (256 / SG_CW) i)
+        // rows of Y the group owns -> LDS (thread: column tid % CW, rows tid / CW + (256 / CW) i)
         {
-            constexpr int RS = 256 / SG_CW;
-            const int j = tid % SG_CW, rq = tid / SG_CW;
+            constexpr int RS = 256 / CW;
+            const int j = tid % CW, rq = tid / CW;
 #pragma unroll
             for (int i = 0; i < MAXBLK * NB / RS; i++) {
                 const int r = rq + RS * i;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
             if (c < nblk) {                                  // uniform over the workgroup
                 const int src = (TRANS || c == b) ? c : b, dst = (TRANS && c != b) ? b : c;
                 const double (&ms)[16 * E] = m[u % NSETS];
-                constexpr int NJB = SG_CW / 16;
+                constexpr int NJB = CW / 16;
                 v4d acc[NJB];
 #pragma unroll
                 for (int jb = 0; jb < NJB; jb++) acc[jb] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -962,8 +962,8 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
             }
         }
         {
-            constexpr int RS = 256 / SG_CW;
-            const int j = tid % SG_CW, rq = tid / SG_CW;
+            constexpr int RS = 256 / CW;
+            const int j = tid % CW, rq = tid / CW;
 #pragma unroll 16
             for (int i = 0; i < MAXBLK * NB / RS; i++) {
                 const int r = rq + RS * i;
@@ -1010,8 +1010,8 @@ __device__ __forceinline__ double keep_if(double v, bool keep)
     return v;
 }
 
-template <int E, int KB>
-__global__ __launch_bounds__(WIDE_THREADS) void k_solve_fwd_wide(
+template <int E, int KB, int NT>
+__global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrr, int j0)
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_fwd_wide(
     constexpr int NJB = NJ / 16;
     constexpr int LD = KB * 64 + 2;       // LDS row stride: 16 j x 2 k of a half-wave on 32 disjoint bank pairs
     constexpr int QC = 16 / E;            // k-steps (of 4 columns) per chunk of the operand ring
-    constexpr int NW = WIDE_THREADS / 64;
+    constexpr int NW = NT / 64;
     __shared__ double Xs[NJ][LD];         // Xs[j][c] = x1[c][j0 + j]
     __shared__ int32_t rows_s[WIDE_MAX_RUN * 64];   // rows of Y the run updates (a load from Ls inside the loop would make
                                                     // the wave wait for every operand request that is in flight)
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_fwd_wide(
     const int ncq = (nq + QC - 1) / QC;                           // chunks per slab
     const int row0 = e.tile0 * 64;                                // first row (below the group) of the run
     const int rows_run = min(64 * min(e.ntiles, WIDE_MAX_RUN), t.nrows - row0);
-    for (int i = tid; i < rows_run; i += WIDE_THREADS) rows_s[i] = Ls[t.ls_off + row0 + i];
+    for (int i = tid; i < rows_run; i += NT) rows_s[i] = Ls[t.ls_off + row0 + i];
     const int nslab = (rows_run + 15) >> 4;
     const int nmine = nslab > w ? (nslab - w + NW - 1) / NW : 0;  // slabs w, w + NW, ...
     const int nch = nmine * ncq;
@@ -1096,19 +1096,32 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_fwd_wide(
         int q2 = 0;
         const double *__restrict__ p2 = AGAIN ? chunk_ptr(ch + 2, q2) : nullptr;
         const double *__restrict__ xs = &Xs[l15][4 * cc * QC + l4];
+        // 8 waves: the x1 operands of k-step qq + 1 are read from LDS while the products of k-step qq run (16 waves have
+        // no registers to spare for that, and four waves per SIMD to cover the read)
+        constexpr bool AHEAD = (NT == 512);
+        double bc[NJB], bn[NJB];
+#pragma unroll
+        for (int jb = 0; jb < NJB; jb++) bc[jb] = xs[16 * jb * LD];
 #pragma unroll
         for (int qq = 0; qq < QC; qq++) {
+            if (qq + 1 < QC && AHEAD) {
+#pragma unroll
+                for (int jb = 0; jb < NJB; jb++) bn[jb] = xs[16 * jb * LD + 4 * (qq + 1)];
+            }
 #pragma unroll
             for (int jb = 0; jb < NJB; jb++) {
-                const double b = xs[16 * jb * LD + 4 * qq];
                 if constexpr (E == 2) {
-                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq], b, P[jb], 0, 0, 0);
-                    Q[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq + 1], b, Q[jb], 0, 0, 0);
+                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq], bc[jb], P[jb], 0, 0, 0);
+                    Q[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * qq + 1], bc[jb], Q[jb], 0, 0, 0);
                 } else {
-                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qq], b, P[jb], 0, 0, 0);
+                    P[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qq], bc[jb], P[jb], 0, 0, 0);
                 }
             }
             if constexpr (AGAIN) load1(a, p2, q2, qq);
+            if (qq + 1 < QC) {
+#pragma unroll
+                for (int jb = 0; jb < NJB; jb++) bc[jb] = AHEAD ? bn[jb] : xs[16 * jb * LD + 4 * (qq + 1)];
+            }
         }
         if (cc == ncq - 1) {
             // the slab is complete: rows rbase + lane/16 + 4g (g = 0..3), real column 16 jb + lane%16

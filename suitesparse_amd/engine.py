@@ -137,9 +137,13 @@ def lib():
     return _LIB
 
 
+def last_error():
+    return lib().mi355_last_error().decode(errors="replace")
+
+
 def _check(rc):
     if rc != 0:
-        raise Mi355Error(rc, lib().mi355_last_error().decode(errors="replace"))
+        raise Mi355Error(rc, last_error())
 
 
 def probe():
@@ -221,12 +225,18 @@ class Comm:
     def rccl(cls, rank, world, device, exchange):
         """RCCL communicator of its own: exchange(id_or_None) hands rank 0's 128-byte id to every rank (any side
         channel: MPI_Bcast, a file, torch.distributed) and returns it"""
+        # rank 0 ALWAYS takes part in the exchange (a collective of the caller's): when it cannot make an id it sends the
+        # error instead, and every rank raises after the exchange -- nobody is left waiting in it
         idb = None
         if rank == 0:
             buf = C.create_string_buffer(128)
-            _check(lib().mi355_rccl_unique_id(buf))
-            idb = buf.raw
+            rc = lib().mi355_rccl_unique_id(buf)
+            idb = buf.raw if rc == 0 else ("error", int(rc), last_error())
         idb = exchange(idb)
+        if isinstance(idb, tuple):
+            raise Mi355Error(idb[1], "rank 0 could not create the RCCL id: " + idb[2])
+        if not isinstance(idb, (bytes, bytearray)) or len(idb) != 128:
+            raise Mi355Error(CHOLMOD_INVALID, "the RCCL id did not arrive")
         h = C.c_void_p()
         _check(lib().mi355_comm_create_rccl(idb, int(rank), int(world), int(device), C.byref(h)))
         return cls(h, int(rank), int(world))

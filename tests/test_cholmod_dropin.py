@@ -691,3 +691,52 @@ def test_every_allocation_failure_falls_back_to_the_cpu(name):
     finally:
         emu.hipcpu_fail_alloc_at(0)
     assert k > 10 and fell_back >= k - 2, (k, fell_back)     # every injected failure ended in a fallback, none in an error
+
+
+@pytest.mark.parametrize("name,world", [("lap3d_8_metis", 2), ("helm3d_6_metis", 3), ("lap2d_16_npd0", 2)])
+def test_n_ranks_through_cholmod(name, world):
+    """cholmod_mi355_register_comm (VERDICT r02 "missing" 5): one THREAD per rank, each with its own cholmod_common, the
+    same matrix and analysis, a blocking transport of Python callbacks as the engine communicator (tests/test_multi_abi.py's
+    Bus); cholmod_l_factorize on every rank = mi355_factor_partition + mi355_factor_numeric_multi + mi355_factor_gather_multi,
+    and every rank's L->x is the complete factor of the fixture (incl. the not-positive-definite protocol: same status,
+    minor and zero pattern on every rank); cholmod_l_solve then runs on each rank's host copy.  CPU build of the engine."""
+    from suitesparse_amd import engine as e, symbolic
+    import test_multi_abi as tm
+    g = load_golden(name)
+    n = g["n"]
+    _cholmod("cpu").close()                     # (skips here when the drop-in build is absent)
+    saved = (e.LIB_PATH, e._LIB)
+    e.LIB_PATH, e._LIB = CPUEMU, None
+    symbolic._ready = False
+    bus = tm.Bus(world)
+    out = [None] * world
+    try:
+        def body(rank):
+            r = _cholmod("cpu")
+            comm = bus.comm(e, rank)
+            assert r.register_comm(comm._h, rank, world) == 1
+            r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+            r.analyze(perm=g["Perm"], supernodal=2)
+            t0 = r.calls_taken()
+            for _ in range(2):                  # the second call refactorizes on the same partition
+                st = r.factorize_full(beta=g["beta"])
+                Lx = r.Lx()
+                X = r.solve(g["B"]) if g["status"] == 0 else None
+            out[rank] = (st, r.info()["minor"], Lx, X, r.calls_taken()[0] - t0[0], r.counters()["cpu_blas_calls"])
+            assert r.register_comm(None, 0, 0) == 1
+            r.close()
+            comm.close()
+        tm.run_ranks(world, body)
+    finally:
+        e.LIB_PATH, e._LIB = saved
+        symbolic._ready = False
+    for rank in range(world):
+        st, minor, Lx, X, taken, cpu_calls = out[rank]
+        assert st == g["status"] and minor == g["minor"], (rank, st, minor)
+        assert taken >= 2 and cpu_calls == 0, (rank, taken, cpu_calls)        # (the counter is the process's: all ranks add to it)
+        assert np.array_equal(Lx == 0, g["Lx"] == 0) and relerr(Lx, g["Lx"]) < 1e-10, rank
+        if g["status"] == 0:
+            A = _dense_A(g) + g["beta"] * np.eye(n)
+            assert relerr(X, np.linalg.solve(A, g["B"])) < 1e-9
+    # every rank made the same collectives in the same order
+    assert all(bus.log[r] == bus.log[0] for r in range(world)) and len(bus.log[0]) > 0
