@@ -430,7 +430,10 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * depth 256, 128 for a complex factor -- instead of one pass per 64-column block; 0: per-block kernels everywhere); key 24:
  * workgroups the tiles of a step are dealt to for the wide kernels (default 256 = one per CU; read when a handle builds its
  * solve lists); key 25: 1 = the forward wide kernel of a real factor with 16 waves per workgroup on long shares (measured
- * 3 % slower at 150^3, default 0); keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * 3 % slower at 150^3, default 0); key 26: 1 = the trailing update of a panel step also factorizes the diagonal block it
+ * completes, in the workgroup of its tile (0, 0) (two dependent launches per 64 columns instead of three; measured + 0.4 %
+ * at 150^3 and 2D 2000^2 while the POTRF time moves into the k_gemm128 launches the roofline is built from, so default 0);
+ * keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -302,9 +302,20 @@ struct HostCopier {
     hipError_t err = hipSuccess;
     size_t next = 0;            // next chunk of F->copy_plan to hand over (main thread)
     // lanes: threads that each own a pinned staging buffer and a stream of the handle (make_lanes)
+    bool started = true;        // false: a lane's thread could not be created (the caller reports out of memory)
     HostCopier(mi355_factor_s *F_, double *dst_) : F(F_), dst(dst_)
     {
-        for (size_t l = 0; l < F->lane_stream.size(); l++) th.emplace_back([this, l] { run(l); });
+        // a std::vector of joinable threads must never be destroyed by an exception: the threads already running are
+        // told to end and joined here, and the caller sees `started == false`
+        try {
+            for (size_t l = 0; l < F->lane_stream.size(); l++) th.emplace_back([this, l] { run(l); });
+        } catch (const std::exception &) {
+            started = false;
+            { std::lock_guard<std::mutex> lk(mu); closed = true; }
+            cv.notify_all();
+            for (std::thread &t : th) if (t.joinable()) t.join();
+            th.clear();
+        }
     }
     ~HostCopier() { (void)finish(); }
     void run(size_t lane)
@@ -369,8 +380,13 @@ struct HostCopier {
 int make_lanes(mi355_factor_s *F)
 {
     if (!F->lane_stream.empty()) return MI355_OK;
-    const int lanes = std::max(1, std::min(32, tuning().host_lanes));
-    F->lane_bytes = (size_t)std::max(1, tuning().host_lane_mb) << 20;
+    // sized by the factor, the largest thing a handle moves: one lane per MB of it up to the tuned number, staging buffers
+    // no larger than a lane's share (a factor of a few KB, as most of a CHOLMOD application's are, pins 64 KB and starts
+    // one thread, not 4 x 32 MB and four)
+    const size_t fbytes = (size_t)F->sym.xsize * (size_t)F->E * sizeof(double);
+    const int lanes = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(32, tuning().host_lanes)), (fbytes + (1u << 20) - 1) >> 20));
+    const size_t share = ((fbytes / (size_t)lanes + 65535) >> 16) << 16;
+    F->lane_bytes = std::max<size_t>(65536, std::min<size_t>((size_t)std::max(1, tuning().host_lane_mb) << 20, share));
     for (int l = 0; l < lanes; l++) {
         void *p = nullptr;
         HIP_TRY(hipHostMalloc(&p, F->lane_bytes, hipHostMallocDefault));
@@ -414,13 +430,15 @@ int lanes_transfer(mi355_factor_s *F, const std::vector<LanePiece> &pieces, bool
         if (e != hipSuccess) { std::lock_guard<std::mutex> lk(mu); err = e; }
     };
     const size_t nl = std::min(F->lane_stream.size(), pieces.size());
-    try {
+    {
+        // (a thread that cannot be created must not take the vector of running threads down with it: the lanes that did
+        // start, and the calling thread, do all the pieces)
         std::vector<std::thread> th;
-        for (size_t l = 1; l < nl; l++) th.emplace_back(work, l);
+        for (size_t l = 1; l < nl; l++) {
+            try { th.emplace_back(work, l); } catch (const std::exception &) { break; }
+        }
         work(0);                                   // the calling thread is lane 0
         for (std::thread &t : th) t.join();
-    } catch (const std::exception &e) {
-        return fail(MI355_OUT_OF_MEMORY, std::string("cannot start the copy threads: ") + e.what());
     }
     if (err != hipSuccess) return fail(MI355_GPU_PROBLEM, std::string("staged copy failed: ") + hipGetErrorString(err));
     return MI355_OK;
@@ -531,14 +549,15 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                     hipLaunchKernelGGL(k_potrf16, dim3((unsigned)((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES)),
                                        dim3(64 * POTRF16_WAVES), 0, F->stream, D.potrf.p + st.first, ord, (int64_t)st.nsmall,
                                        F->Lx.p, F->Dinv.p, F->info.p);
-                if (st.count > st.nsmall)
-                    hipLaunchKernelGGL(k_potrf64, dim3((unsigned)(st.count - st.nsmall)), dim3(256), 0, F->stream,
+                // (the last nfused tasks of the step were factorized by the trailing update that completed them)
+                if (st.count - st.nfused > st.nsmall)
+                    hipLaunchKernelGGL(k_potrf64, dim3((unsigned)(st.count - st.nfused - st.nsmall)), dim3(256), 0, F->stream,
                                        D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p, ord + st.nsmall);
-            } else
-                hipLaunchKernelGGL(k_potrf64, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+            } else if (st.count > st.nfused)
+                hipLaunchKernelGGL(k_potrf64, dim3((unsigned)(st.count - st.nfused)), dim3(256), 0, F->stream,
                                    D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p, (const int32_t *)nullptr);
             tm.end(1);
-            F->st_npotrf += 1;
+            if (st.count > st.nfused) F->st_npotrf += 1;
         } else {
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
@@ -548,7 +567,7 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                 hipLaunchKernelGGL(cplx ? k_gemm128<true> : k_gemm128<false>, dim3((unsigned)st.ntiles),
                                    dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p,
-                                   (unsigned long long *)nullptr);
+                                   (unsigned long long *)nullptr, (const PotrfTask *)D.potrf.p, F->Dinv.p, F->info.p);
             else if (cplx)
                 hipLaunchKernelGGL(k_gemm64c, dim3((unsigned)st.ntiles), dim3(256), 0, q,
                                    D.gemm.p + st.first, D.gemm_tmap.p + st.tmap_off, F->Lx.p, F->Dinv.p, D.relmap.p);
@@ -909,6 +928,7 @@ int copy_all_to_host(mi355_factor_s *F, double *host_Lx)
     HIP_TRY(hipEventRecord(F->copy_ev[0], F->stream));
     try {
         HostCopier hc(F, host_Lx);
+        if (!hc.started) return fail(MI355_OUT_OF_MEMORY, "cannot start the copy threads");
         rc = hc.hand_over_range(F->copy_ev[0], 0, F->sym.xsize);
         const int rc2 = hc.finish();
         return rc ? rc : rc2;
@@ -944,6 +964,7 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
         } catch (const std::exception &e) {       // no thread to be had: nothing was started
             return fail(MI355_OUT_OF_MEMORY, std::string("cannot start the copy thread: ") + e.what());
         }
+        if (!hc->started) { hc.reset(); return fail(MI355_OUT_OF_MEMORY, "cannot start the copy threads"); }
     }
     F->numeric_ok = false;
     F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
@@ -2104,6 +2125,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 23) tuning().solve_wide = value ? 1 : 0;
     else if (key == 24) tuning().solve_wide_wgs = std::max(1, value);
     else if (key == 25) tuning().solve_wide_1024 = value ? 1 : 0;
+    else if (key == 26) tuning().fuse_potrf = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }
@@ -2126,7 +2148,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
     GemmTask t;
     t.a_off = 0; t.b_off = 0; t.c_off = (int64_t)lda * K; t.rm_off = -1;
     t.lda = (int32_t)lda; t.ldb = (int32_t)lda; t.ldc = M; t.M = M; t.N = N; t.K = K;
-    t.mode = GEMM_DIRECT_SUB; t.big = kernel; t.tile0 = 0;
+    t.mode = GEMM_DIRECT_SUB; t.big = kernel; t.tile0 = 0; t.fuse_potrf = -1; t.pad = 0;
     DevBuf<GemmTask> dt;
     HIP_TRY(dt.upload(&t, 1, 0));
     const int64_t ntiles = gemm_tiles(M, N, t.mode, kernel ? BTILE : TILE);
@@ -2151,7 +2173,7 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
         if (it == 0) HIP_TRY(hipEventRecord(e0, 0));
         if (kernel >= 1)
             hipLaunchKernelGGL(k_gemm128<false>, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr,
-                               dstamps.p);
+                               dstamps.p, (const PotrfTask *)nullptr, (double *)nullptr, (int *)nullptr);
         else
             hipLaunchKernelGGL(k_gemm64, dim3((unsigned)ntiles), dim3(256), 0, 0, dt.p, dmap.p, buf.p, buf.p, (const int32_t *)nullptr);
     }

@@ -390,11 +390,22 @@ constexpr int G128_LD = 144;        // 1152 B row stride: +32 banks per k row =>
 // Only the staging addresses and the index arithmetic of the epilogues change; a tile covers 128 real rows
 // = 64 complex rows by 128 complex columns (the host builds the tile table for that shape, GemmTask::big = 2).
 // The imaginary part of a diagonal entry of C is left alone (it is zero, as zherk keeps it).
+template <bool FRESH>
+__device__ __forceinline__ void potrf64_block(
+    const PotrfTask &t, double *Lx, double *Dinv, int *info, double (*Ls)[NB + 1], double (*Vs)[NB + 1]);
+
+// Fused POTRF (GemmTask::fuse_potrf, real factors): the trailing update of a panel step is the last writer of the next
+// diagonal block, and that block lies in tile (0, 0) of the task.  The workgroup of that tile factorizes it (and builds its
+// inverse) right after its own stores -- potrf64_block on the LDS of the main loop -- so the panel chain of a wide
+// supernode is two dependent launches per 64 columns (TRSM, trailing update) instead of three, and the 35-45 us of the
+// single-workgroup POTRF run beside the other tiles of the update instead of after them.  potrf / dinv_w / info: the
+// schedule's POTRF tasks, the block inverses (written here; `Dinv` is the read-only view of the TRSM tasks), LAPACK's info.
 template <bool CPLX>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
     const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
     const double *__restrict__ Dinv, const int32_t *__restrict__ relmap,
-    unsigned long long *__restrict__ stamps)       // debug builds of the micro-benchmark only: 4 clock stamps per tile
+    unsigned long long *__restrict__ stamps,       // debug builds of the micro-benchmark only: 4 clock stamps per tile
+    const PotrfTask *__restrict__ potrf = nullptr, double *dinv_w = nullptr, int *info = nullptr)
 {
     const unsigned long long st0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     __shared__ double As[2][G128_KS][G128_LD];
@@ -558,11 +569,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
             buf ^= 1;
         }
     };
+    // (uniform over the workgroup)
+    const bool fused = !CPLX && mode == GEMM_DIRECT_SUB && t.fuse_potrf >= 0 && te.tmtn == 0u && potrf != nullptr;
     if (skip_mma) {
         mainloop(std::false_type{});
-        return;
+        if (!fused) return;
+    } else {
+        mainloop(std::true_type{});
     }
-    mainloop(std::true_type{});
     const unsigned long long st2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const int64_t ldc = E * (int64_t)t.ldc;
@@ -578,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
         // the wave waits for memory once per batch instead of once per element
 #pragma unroll
         for (int mi = 0; mi < 4; mi++) {
+            if (skip_mma) break;                 // (a wave that only came along for the fused POTRF below)
             const int m = m0 + wm * 64 + mi * 16 + l15;
             double cv[16];
 #pragma unroll
@@ -596,6 +611,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
             __builtin_amdgcn_s_waitcnt(0);
             stamps[4 * bid] = st0; stamps[4 * bid + 1] = st1; stamps[4 * bid + 2] = st2;
             stamps[4 * bid + 3] = __builtin_amdgcn_s_memtime();
+        }
+        if constexpr (!CPLX) {
+            if (fused) {
+                // the stores above are complete and visible to this workgroup's loads before anybody reads the block
+                __threadfence();
+                __syncthreads();
+                static_assert(sizeof(As) >= sizeof(double) * NB * (NB + 1) && sizeof(Bs) >= sizeof(double) * NB * (NB + 1),
+                              "the POTRF images reuse the staging buffers of the main loop");
+                potrf64_block<true>(potrf[t.fuse_potrf], Lx, dinv_w, info,
+                                    reinterpret_cast<double (*)[NB + 1]>(&As[0][0][0]),
+                                    reinterpret_cast<double (*)[NB + 1]>(&Bs[0][0][0]));
+            }
         }
         return;
     }
@@ -705,24 +732,28 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane)      // srcl
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void k_potrf64(
-    const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
-    double *__restrict__ Dinv, int *__restrict__ info, const int32_t *__restrict__ order = nullptr)
+// The work of one workgroup (256 threads) on one block; Ls / Vs: two LDS images of NB x (NB + 1) doubles.
+// FRESH: the block was written by THIS workgroup a moment ago (k_gemm128's fused call: its read-modify-write stores,
+// made visible by a fence and a barrier): the loads bypass the vector L1, whose lines may predate those stores.
+template <bool FRESH>
+__device__ __forceinline__ void potrf64_block(
+    const PotrfTask &t, double *Lx, double *Dinv, int *info, double (*Ls)[NB + 1], double (*Vs)[NB + 1])
 {
-    __shared__ double Ls[NB][NB + 1];       // the block, factorized in place (row i, column j)
-    __shared__ double Vs[NB][NB + 1];       // its inverse
-    const PotrfTask t = tasks[order ? order[blockIdx.x] : (int)blockIdx.x];
     const int tid = threadIdx.x;
     const int nb = t.nb;
     const int64_t lda = t.lda;
-    double *__restrict__ A = Lx + t.a_off;
+    double *A = Lx + t.a_off;
 
     const int nblk = (nb + 15) >> 4;                          // 16-column blocks that hold anything
     const int np = nblk * 16;                                 // padded order: identity beyond nb
     for (int idx = tid; idx < np * np; idx += 256) {
         const int i = idx % np, j = idx / np;
         double v = (i == j) ? 1.0 : 0.0;                     // identity padding
-        if (i < nb && j < nb) v = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
+        if (i < nb && j < nb) {
+            if (i >= j) v = FRESH ? __hip_atomic_load(A + i + (int64_t)j * lda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : A[i + (int64_t)j * lda];
+            else v = 0.0;
+        }
         Ls[i][j] = v;
         Vs[i][j] = 0.0;
     }
@@ -826,12 +857,22 @@ __global__ __launch_bounds__(256) void k_potrf64(
         __syncthreads();
     }
     if (t.dinv_off >= 0) {
-        double *__restrict__ D = Dinv + t.dinv_off;
+        double *D = Dinv + t.dinv_off;
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx % nb, j = idx / nb;
             D[idx] = (i >= j) ? Vs[i][j] : 0.0;               // column-major, ld = nb
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_potrf64(
+    const PotrfTask *__restrict__ tasks, double *__restrict__ Lx,
+    double *__restrict__ Dinv, int *__restrict__ info, const int32_t *__restrict__ order = nullptr)
+{
+    __shared__ double Ls[NB][NB + 1];       // the block, factorized in place (row i, column j)
+    __shared__ double Vs[NB][NB + 1];       // its inverse
+    const PotrfTask t = tasks[order ? order[blockIdx.x] : (int)blockIdx.x];
+    potrf64_block<false>(t, Lx, Dinv, info, Ls, Vs);
 }
 
 //------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #include "schedule.hpp"
 #include <cmath>
 #include <algorithm>
+#include <unordered_map>
 #include <cstdio>
 
 namespace mi355 {
@@ -93,7 +94,7 @@ GemmTask make_gemm(int64_t a, int64_t b, int64_t c, int64_t rm, int64_t lda, int
     t.a_off = a; t.b_off = b; t.c_off = c; t.rm_off = rm;
     t.lda = (int32_t)lda; t.ldb = (int32_t)ldb; t.ldc = (int32_t)ldc;
     t.M = (int32_t)M; t.N = (int32_t)N; t.K = (int32_t)K;
-    t.mode = mode; t.big = 0; t.tile0 = 0;
+    t.mode = mode; t.big = 0; t.tile0 = 0; t.fuse_potrf = -1; t.pad = 0;
     return t;
 }
 
@@ -461,6 +462,9 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
 
     // ---- flatten into launch order
     size_t awaited = 0;                             // DistTop: broadcasts [0, awaited) have their wait point
+    std::unordered_map<int64_t, int64_t> fused_by;  // diagonal block (its offset in Lx) -> the trailing task of the previous
+                                                    // iteration that completes it and factorizes it in its tile (0, 0)
+    const bool truncated_any = false;               // (the truncated replay fuses as well: same tasks, fewer of them)
     for (int lev = 0; lev < nlev; lev++) {
         LevelSteps &ls = L[lev];
         std::vector<GemmTask> deferred;             // DistTop look-ahead: far updates waiting for the next broadcast point
@@ -485,6 +489,8 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 out.dinv_size += (int64_t)pt.nb * pt.nb;
                 if (own) pts.push_back(pt);
             }
+            if (!fused_by.empty())
+                std::stable_partition(pts.begin(), pts.end(), [&](const PotrfTask &pt) { return fused_by.count(pt.a_off) == 0; });
             int64_t stiles = 0;
             const int64_t tmap_off = (int64_t)out.solve_tile_task.size();
             int32_t ti32 = 0;
@@ -500,12 +506,22 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.kind = STEP_POTRF; st.level = lev; st.big = 0; st.trsm = 0; st.flags = 0; st.nsmall = 0;
             st.first = (int64_t)out.potrf.size();
             st.count = (int64_t)pts.size();
+            // blocks that the previous iteration's trailing update completes inside k_gemm128 (the workgroup of tile
+            // (0, 0) factorizes the block right after its stores): they come last in the step and have no launch here
+            for (size_t i = 0; i < pts.size(); i++)
+                if (fused_by.count(pts[i].a_off)) {
+                    out.gemm[(size_t)fused_by[pts[i].a_off]].fuse_potrf = (int32_t)(st.first + (int64_t)i);
+                    st.nfused++;
+                }
             if (tuning().tiny_max > 0 && !S.cplx) {
                 out.potrf_order.resize(out.potrf.size());           // steps of other schedules' making: none
-                for (int pass = 0; pass < 2; pass++)
-                    for (size_t i = 0; i < pts.size(); i++)
-                        if ((pts[i].nb <= 16) == (pass == 0)) out.potrf_order.push_back((int32_t)i);
-                for (auto &pt : pts) st.nsmall += (pt.nb <= 16) ? 1 : 0;
+                for (int pass = 0; pass < 3; pass++)
+                    for (size_t i = 0; i < pts.size(); i++) {
+                        const bool fz = fused_by.count(pts[i].a_off) != 0;
+                        const int cls = fz ? 2 : (pts[i].nb <= 16 ? 0 : 1);
+                        if (cls == pass) out.potrf_order.push_back((int32_t)i);
+                    }
+                for (auto &pt : pts) st.nsmall += (pt.nb <= 16 && !fused_by.count(pt.a_off)) ? 1 : 0;
             }
             st.ntiles = st.count;
             st.stiles = stiles;
@@ -537,9 +553,20 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             }
             // an iteration that ends an outer block: its update of the next block waits for the previous far
             // part (same target columns), its own far part then goes to the side stream
+            const size_t g0 = out.gemm.size();
             flush_gemm(out, ls.trail[it], lev, S, 0, ls.rest[it].empty() ? 0 : STEP_JOIN);
+            fused_by.clear();
+            if (tuning().fuse_potrf && !S.cplx && !tuning().lookahead && !truncated_any) {
+                // The one trailing task of a supernode at this iteration is the last writer of its next diagonal block
+                // (target origin c_off = that block): routed to the big-tile kernel, its tile (0, 0) holds the block
+                for (size_t g = g0; g < out.gemm.size(); g++) {
+                    const GemmTask &t = out.gemm[g];
+                    if (t.big == 1 && t.mode == GEMM_DIRECT_SUB) fused_by[t.c_off] = (int64_t)g;
+                }
+            }
             flush_gemm(out, ls.rest[it], lev, S, 0, STEP_SIDE);
         }
+        fused_by.clear();
         if (!deferred.empty()) flush_gemm(out, deferred, lev, S, 0, 0);
         for (size_t k = awaited; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
         awaited = out.bcasts.size();
@@ -807,6 +834,7 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
     auto bad = [&](const char *what, int64_t i) { snprintf(buf, sizeof buf, "%s %lld out of bounds", what, (long long)i); return std::string(buf); };
     // last entry a column-major block (rows x cols, ld) reaches, from off
     auto last = [](int64_t off, int64_t rows, int64_t cols, int64_t ld) { return off + (rows - 1) + (cols - 1) * ld; };
+    int64_t nfused_refs = 0, nfused_steps = 0;
     for (size_t i = 0; i < sc.gemm.size(); i++) {
         const GemmTask &t = sc.gemm[i];
         if (t.M <= 0 || t.N <= 0 || t.K <= 0 || t.lda < t.M || t.ldc <= 0) return bad("gemm task shape", (int64_t)i);
@@ -825,6 +853,14 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         } else {
             if (t.N > t.M) return bad("gemm task N > M", (int64_t)i);
             if (t.b_off < 0 || last(t.b_off, t.N, t.K, t.ldb) >= xs) return bad("gemm task B", (int64_t)i);
+        }
+        if (t.fuse_potrf >= 0) {
+            // the block this update completes: a POTRF task at the update's target origin, inside tile (0, 0) of a
+            // big-tile, plain (unscattered) update of a real factor
+            if (t.fuse_potrf >= (int64_t)sc.potrf.size() || t.mode != GEMM_DIRECT_SUB || t.big != 1 || S.cplx) return bad("gemm task fused potrf", (int64_t)i);
+            const PotrfTask &pt = sc.potrf[(size_t)t.fuse_potrf];
+            if (pt.a_off != t.c_off || pt.lda != t.ldc || pt.nb > t.N || pt.nb > t.M) return bad("gemm task fused potrf block", (int64_t)i);
+            nfused_refs++;
         }
         if (t.mode == GEMM_SCATTER_SUB) {
             if (t.rm_off < 0 || t.rm_off + t.M > rs) return bad("gemm task relative map", (int64_t)i);
@@ -853,15 +889,21 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
             if (st.first + st.count > (int64_t)sc.potrf.size()) return bad("potrf step range", (int64_t)i);
             if (!sc.potrf_order.empty()) {
                 // the order list of the step: a permutation of its tasks, the nsmall blocks of <= 16 columns first
-                if (sc.potrf_order.size() != sc.potrf.size() || st.nsmall < 0 || st.nsmall > st.count) return bad("potrf order list", (int64_t)i);
+                if (sc.potrf_order.size() != sc.potrf.size() || st.nsmall < 0 || st.nsmall > st.count - st.nfused) return bad("potrf order list", (int64_t)i);
                 std::vector<uint8_t> seen((size_t)st.count, 0);
                 for (int64_t k = 0; k < st.count; k++) {
                     const int32_t o = sc.potrf_order[(size_t)(st.first + k)];
                     if (o < 0 || o >= st.count || seen[(size_t)o]) return bad("potrf order entry of step", (int64_t)i);
                     seen[(size_t)o] = 1;
-                    if ((sc.potrf[(size_t)(st.first + o)].nb <= 16) != (k < st.nsmall)) return bad("potrf order class of step", (int64_t)i);
+                    // the launched tasks: blocks of <= 16 columns first; the fused ones (the last nfused tasks of the step) last
+                    if (k < st.count - st.nfused) {
+                        if (o >= st.count - st.nfused) return bad("potrf order: fused task among the launched", (int64_t)i);
+                        if ((sc.potrf[(size_t)(st.first + o)].nb <= 16) != (k < st.nsmall)) return bad("potrf order class of step", (int64_t)i);
+                    } else if (o < st.count - st.nfused) return bad("potrf order: launched task among the fused", (int64_t)i);
                 }
             } else if (st.nsmall != 0) return bad("potrf step without order list", (int64_t)i);
+            if (st.nfused < 0 || st.nfused > st.count) return bad("potrf step fused count", (int64_t)i);
+            nfused_steps += st.nfused;
             if (st.tmap_off < 0 || st.tmap_off + st.stiles > (int64_t)sc.solve_tile_task.size()) return bad("potrf step solve tiles", (int64_t)i);
             for (int64_t b = 0; b < st.stiles; b++) {
                 const int32_t ti = sc.solve_tile_task[(size_t)(st.tmap_off + b)];
@@ -888,6 +930,7 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
             }
         }
     }
+    if (nfused_refs != nfused_steps) return bad("fused potrf tasks without an update that runs them", nfused_steps - nfused_refs);
     for (size_t i = 0; i < sc.bcasts.size(); i++) {
         const BcastPoint &b = sc.bcasts[i];
         if (b.lo < 0 || b.count <= 0 || b.lo + b.count > xs || b.step < 0 || b.step > (int64_t)sc.steps.size() || b.root < 0)

@@ -44,6 +44,10 @@ struct GemmTask {
     int32_t mode;
     int32_t big;        // 1: tiles counted with BTILE (big-tile kernel), 0: TILE
     int64_t tile0;      // first tile of this task inside its launch
+    int32_t fuse_potrf; // >= 0: index (in Schedule::potrf) of the diagonal block that this trailing update completes -- the
+                        // workgroup of tile (0, 0) factorizes it right after its stores (k_gemm128), and the next POTRF
+                        // step has no launch for it; -1: none
+    int32_t pad;
 };
 
 struct PotrfTask {
@@ -146,6 +150,9 @@ struct Step {
     int32_t flags;      // STEP_SIDE / STEP_JOIN / STEP_TINY
     int32_t nsmall;     // STEP_POTRF with Schedule::potrf_order: the first nsmall entries of the step's order list are
                         // blocks of at most 16 columns (k_potrf16: one wave per block), the rest go to k_potrf64
+    int32_t nfused = 0; // STEP_POTRF: the LAST nfused tasks of the step are factorized by the trailing update that completes
+                        // them (GemmTask::fuse_potrf) and have no launch here; the solves still see them as tasks of the step
+    int32_t pad = 0;
 };
 // Look-ahead: the part of an outermost trailing update that lies beyond the NEXT outer block does not feed the
 // next block's panel chain, so it runs on a second stream (STEP_SIDE) next to that chain; whatever touches its
@@ -248,7 +255,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax = 0 /* 256 real, 128 complex; 0: no wide lists */);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -305,6 +305,9 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __builtin_amdgcn_readlane(v, l) hipcpu::readlane((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) hipcpu::readfirstlane((v))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __threadfence() ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ULL)
 #define __builtin_amdgcn_s_memrealtime() (0ULL)
@@ -327,6 +330,7 @@ using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #include <chrono>
 #include <cstdlib>
 #include <atomic>
+#include <map>
 #include <deque>
 #include <memory>
 #include <tuple>
@@ -536,13 +540,29 @@ __attribute__((visibility("default"), used)) inline long hipcpu_alloc_calls() { 
 __attribute__((visibility("default"), used)) inline long hipcpu_live_allocs() { return hipcpu::alloc_live.load(); }
 __attribute__((visibility("default"), used)) inline void hipcpu_set_free_memory(long long b) { hipcpu::mem_free_override = b; }
 }
+namespace hipcpu {
+inline std::mutex pinned_mu;
+inline std::map<void *, size_t> pinned_sizes;           // pinned allocations and their sizes (hipcpu_pinned_bytes)
+}
+extern "C" __attribute__((visibility("default"), used)) inline long long hipcpu_pinned_bytes()
+{
+    std::lock_guard<std::mutex> lk(hipcpu::pinned_mu);
+    long long t = 0;
+    for (auto &kv : hipcpu::pinned_sizes) t += (long long)kv.second;
+    return t;
+}
 inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned)
 {
     *p = hipcpu::alloc_should_fail() ? nullptr : std::malloc(bytes ? bytes : 1);
-    if (*p) hipcpu::alloc_live++;
+    if (*p) { hipcpu::alloc_live++; std::lock_guard<std::mutex> lk(hipcpu::pinned_mu); hipcpu::pinned_sizes[*p] = bytes; }
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
-inline hipError_t hipHostFree(void *p) { if (p) hipcpu::alloc_live--; std::free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void *p)
+{
+    if (p) { hipcpu::alloc_live--; std::lock_guard<std::mutex> lk(hipcpu::pinned_mu); hipcpu::pinned_sizes.erase(p); }
+    std::free(p);
+    return hipSuccess;
+}
 inline hipError_t hipMalloc(void **p, size_t bytes)
 {
     *p = hipcpu::alloc_should_fail() ? nullptr : std::malloc(bytes ? bytes : 1);

@@ -104,34 +104,7 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
     for (const UpdatePair &u : sc.pairs)
         for (int i = 0; i < u.ndrow2; i++)
             relmap[u.rm_off + i] = find_row(S.Ls + u.ls_dst, u.nsrow, S.Ls[u.ls_src + i]);
-    std::vector<double> C;
-    for (int64_t si = step0; si < step1; si++) {
-        const Step &st = sc.steps[(size_t)si];
-        if (st.kind == STEP_POTRF) {
-            std::vector<int64_t> todo;
-            if (hostrun::use_device_source >= 3) {
-                // exactly the engine's POTRF launches (run_schedule)
-                if (!sc.potrf_order.empty()) {
-                    const int32_t *ord = sc.potrf_order.data() + st.first;
-                    if (st.nsmall > 0)
-                        hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
-                            k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
-                    if (st.count > st.nsmall)
-                        hipcpu::launch(st.count - st.nsmall, 256, [&] {
-                            k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), ord + st.nsmall); });
-                } else
-                    hipcpu::launch(st.count, 256, [&] { k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), nullptr); });
-            } else if (hostrun::use_device_source >= 2 && !sc.potrf_order.empty()) {
-                // the engine's launches: k_potrf16 (from its own source) over the first nsmall entries of the order
-                // list, the wider blocks by the loops below
-                const int32_t *ord = sc.potrf_order.data() + st.first;
-                if (st.nsmall > 0)
-                    hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
-                        k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
-                for (int64_t k = st.nsmall; k < st.count; k++) todo.push_back(st.first + ord[k]);
-            } else
-                for (int64_t ti = st.first; ti < st.first + st.count; ti++) todo.push_back(ti);
-            for (int64_t ti : todo) {
+    auto host_potrf = [&](int64_t ti) {
                 const PotrfTask &t = sc.potrf[ti];
                 double *A = Lx + t.a_off; int nb = t.nb; int64_t lda = t.lda;
                 bool failed = false;
@@ -162,13 +135,42 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                         for (int c = 0; c < nb; c++) A[r + c * lda] = xr[c];
                     }
                 }
-            }
+    };
+    std::vector<double> C;
+    for (int64_t si = step0; si < step1; si++) {
+        const Step &st = sc.steps[(size_t)si];
+        if (st.kind == STEP_POTRF) {
+            std::vector<int64_t> todo;
+            if (hostrun::use_device_source >= 3) {
+                // exactly the engine's POTRF launches (run_schedule)
+                if (!sc.potrf_order.empty()) {
+                    const int32_t *ord = sc.potrf_order.data() + st.first;
+                    if (st.nsmall > 0)
+                        hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
+                            k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
+                    if (st.count - st.nfused > st.nsmall)
+                        hipcpu::launch(st.count - st.nfused - st.nsmall, 256, [&] {
+                            k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), ord + st.nsmall); });
+                } else if (st.count > st.nfused)
+                    hipcpu::launch(st.count - st.nfused, 256, [&] { k_potrf64(sc.potrf.data() + st.first, Lx, Dinv.data(), info.data(), nullptr); });
+            } else if (hostrun::use_device_source >= 2 && !sc.potrf_order.empty()) {
+                // the engine's launches: k_potrf16 (from its own source) over the first nsmall entries of the order
+                // list, the wider blocks by the loops below
+                const int32_t *ord = sc.potrf_order.data() + st.first;
+                if (st.nsmall > 0)
+                    hipcpu::launch((st.nsmall + POTRF16_WAVES - 1) / POTRF16_WAVES, 64 * POTRF16_WAVES, [&] {
+                        k_potrf16(sc.potrf.data() + st.first, ord, (int64_t)st.nsmall, Lx, Dinv.data(), info.data()); });
+                for (int64_t k = st.nsmall; k < st.count - st.nfused; k++) todo.push_back(st.first + ord[k]);
+            } else
+                for (int64_t ti = st.first; ti < st.first + st.count - st.nfused; ti++) todo.push_back(ti);   // (the fused ones are last)
+            for (int64_t ti : todo) host_potrf(ti);
         } else if (hostrun::use_device_source >= 3 && !(st.flags & STEP_TINY)) {
             // exactly the engine's GEMM launches of a real factor
             const GemmTask *tk = sc.gemm.data() + st.first;
             const Schedule::TileEntry *tm = sc.gemm_tile_tab.data() + st.tmap_off;
             if (st.big)
-                hipcpu::launch(st.ntiles, 256, [&] { k_gemm128<false>(tk, tm, Lx, Dinv.data(), relmap.data(), (unsigned long long *)nullptr); });
+                hipcpu::launch(st.ntiles, 256, [&] { k_gemm128<false>(tk, tm, Lx, Dinv.data(), relmap.data(), (unsigned long long *)nullptr,
+                                                                       sc.potrf.data(), Dinv.data(), info.data()); });
             else if (st.trsm)
                 hipcpu::launch(st.ntiles, 256, [&] { k_trsm64(tk, tm, Lx, Dinv.data()); });
             else
@@ -206,6 +208,10 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
                     }
             }
             if (tiles != st.ntiles || !check_tile_table(sc, st)) info[S.nsuper + 1] = -1;
+            // the diagonal blocks that these trailing updates complete (GemmTask::fuse_potrf): k_gemm128 factorizes them
+            // in its tile (0, 0); the host loops do it here, after the step
+            for (int64_t ti = st.first; ti < st.first + st.count; ti++)
+                if (sc.gemm[(size_t)ti].fuse_potrf >= 0) host_potrf(sc.gemm[(size_t)ti].fuse_potrf);
         }
     }
 }
@@ -226,6 +232,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 11) tuning().solve_bwd_div = value;
     else if (key == 13) tuning().solve_bwd_div_mma = value;
     else if (key == 14) tuning().tiny_max = value;
+    else if (key == 26) tuning().fuse_potrf = value;
     else if (key == 100) hostrun::use_device_source = value;    // run the product's host-runnable kernels
 }
 
@@ -319,7 +326,7 @@ int emu_check_wide_task(int64_t M, int64_t N, int big)
     GemmTask t;
     t.a_off = 0; t.b_off = 0; t.c_off = M; t.rm_off = -1;
     t.lda = (int32_t)M; t.ldb = (int32_t)M; t.ldc = (int32_t)M;
-    t.M = (int32_t)M; t.N = (int32_t)N; t.K = 1; t.mode = GEMM_DIRECT_SUB; t.big = big; t.tile0 = 0;
+    t.M = (int32_t)M; t.N = (int32_t)N; t.K = 1; t.mode = GEMM_DIRECT_SUB; t.big = big; t.tile0 = 0; t.fuse_potrf = -1; t.pad = 0;
     sc.gemm.push_back(t);
     const std::string e = check_schedule_bounds(S, sc);
     if (e.empty()) return 0;

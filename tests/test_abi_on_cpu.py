@@ -511,3 +511,23 @@ def test_solve_recovers_after_a_failed_allocation(engine):
     assert failed >= 2
     L.close()
     assert emu.hipcpu_live_allocs() == base_live
+
+
+def test_copy_lanes_are_sized_by_the_factor(engine):
+    """every factor that is copied to the host (mi355_factor_numeric_host: each cholmod_factor of the
+    drop-in) used to pin 4 x 32 MB and start four threads whatever its size.  The lanes are now sized by the factor: a
+    factor of a few KB pins 64 KB in one lane; a larger one gets more lanes, never more than its own size rounded up."""
+    import ctypes as C
+    emu = engine.lib()
+    emu.hipcpu_pinned_bytes.restype = C.c_longlong
+    base = emu.hipcpu_pinned_bytes()
+    for name, most in (("demo_bcsstk01", 1 << 16), ("lap3d_8_metis", 1 << 20)):
+        g = load_golden(name)
+        L = engine.SupernodalFactor(sym_of(g), xtype=2 if g["xtype"] == 2 else 1)
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        assert L.numeric_host(beta=g["beta"])[0] == g["status"]
+        pinned = emu.hipcpu_pinned_bytes() - base
+        fbytes = int(g["xsize"]) * 8
+        assert 0 < pinned <= max(most, 2 * fbytes), (name, pinned, fbytes)
+        L.close()
+        assert emu.hipcpu_pinned_bytes() == base
