@@ -433,7 +433,11 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * 3 % slower at 150^3, default 0); key 26: 1 = the trailing update of a panel step also factorizes the diagonal block it
  * completes, in the workgroup of its tile (0, 0) (two dependent launches per 64 columns instead of three; measured + 0.4 %
  * at 150^3 and 2D 2000^2 while the POTRF time moves into the k_gemm128 launches the roofline is built from, so default 0);
- * keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * key 27: deterministic mode (default 0): the scatter updates of an etree level are launched in rounds that hold at most
+ * one descendant per ancestor, so every entry of L receives its additions in one fixed order and two factorizations of the
+ * same matrix give identical bits, as the reference's sequential loop over the descendants does (the default adds with FP64
+ * atomics in whatever order the workgroups arrive: last bits differ from run to run); costs as many launch groups per level
+ * as the busiest ancestor has descendants on it; keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -1561,7 +1561,10 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
     double *const Xcol = X;
     const int64_t dcol = d;
     // measured crossover of the grouped scalar and MFMA sweeps: 5 right-hand sides (real), 3 (complex)
-    const bool mma = nr >= (cplx ? std::min(tuning().solve_mma_min, tuning().solve_mma_min_c) : tuning().solve_mma_min);
+    // (with the wide sweeps a complex factor takes the MFMA path from one right-hand side on: their 16-column variants read
+    // L at the rate of the scalar kernels of a real factor, which a complex factor has no grouped version of)
+    const bool mma = nr >= (cplx ? std::min(tuning().solve_mma_min, (tuning().solve_wide && tuning().solve_group) ? 1 : tuning().solve_mma_min_c)
+                                 : tuning().solve_mma_min);
     const int nrr = nr * F->E;                          // real columns of the row-major image
     if (!cplx && !mma && nr <= SOLVE_NR && tuning().solve_group) {
         // few right-hand sides: the sweep is a chain of dependent launches -- two per SOLVE_GROUP blocks
@@ -1674,7 +1677,8 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             const int32_t *ptmap = wide ? DS.sntmap.p + st.ntmap_off : DS.stmap.p + st.tmap_off;
             const int group = (int)std::min<int64_t>(16, std::max<int64_t>(1, ptiles / std::max(1, tuning().solve_fwd_div_mma)));
             const unsigned grid = (unsigned)((ptiles + group - 1) / group);
-            const int wnj = 64 * F->E;                  // real columns of Y per pass of the wide kernels
+            const bool few = nrr <= 16;                 // a few right-hand sides: the wide kernels' 16-column variants
+            const int wnj = few ? 16 : 64 * F->E;       // real columns of Y per pass of the wide kernels
             int64_t wt64 = 0;                           // 64-row tiles of the step's wide tasks
             if (wide) for (int64_t u = 0; u < st.wcount; u++) wt64 += (DS.ssched.wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
             if (wide && st.wrcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
@@ -1693,7 +1697,13 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                         // real factor: 16 waves per workgroup (4 per SIMD: the kernel fits 128 registers) once the shares are
                         // long enough to give every wave a slab (tuning key 25)
                         const bool big = tuning().solve_wide_1024 && st.wgcount > 0 && wt64 >= 4 * st.wgcount;
-                        if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2, WIDE_THREADS>));
+                        if (few) {
+                            // at most 16 real columns: one j-block per workgroup, an eighth of the products
+                            if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2, WIDE_THREADS, 1>));
+                            else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2, WIDE_THREADS, 1>));
+                            else MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS, 1>));
+                        }
+                        else if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2, WIDE_THREADS>));
                         else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2, WIDE_THREADS>));
                         else if (big) MI355_WIDE_T((k_solve_fwd_wide<1, 4, 1024>), 1024);
                         else MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS>));
@@ -1703,7 +1713,12 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                 const SolveRange *pruns = wide ? DS.snranges_mma.p + st.nrmfirst : DS.sranges_mma.p + st.rmfirst;
                 if (wide && st.wrcount > 0)
                     for (int j0 = 0; j0 < nrr; j0 += wnj) {
-                        if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2>));
+                        if (few) {
+                            if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2, 1>));
+                            else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_bwd_wide<1, 2, 1>));
+                            else MI355_WIDE((k_solve_bwd_wide<1, 4, 1>));
+                        }
+                        else if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2>));
                         else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_bwd_wide<1, 2>));
                         else MI355_WIDE((k_solve_bwd_wide<1, 4>));
 #undef MI355_WIDE
@@ -2126,6 +2141,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 24) tuning().solve_wide_wgs = std::max(1, value);
     else if (key == 25) tuning().solve_wide_1024 = value ? 1 : 0;
     else if (key == 26) tuning().fuse_potrf = value ? 1 : 0;
+    else if (key == 27) tuning().deterministic = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -570,6 +570,27 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
         if (!deferred.empty()) flush_gemm(out, deferred, lev, S, 0, 0);
         for (size_t k = awaited; k < out.bcasts.size(); k++) out.bcasts[k].wait_step = (int64_t)out.steps.size();
         awaited = out.bcasts.size();
+        if (tuning().deterministic && !dist && ls.updates.size() > 1) {
+            // Deterministic mode (tuning key 27): the scatter updates of a level add into their ancestors with FP64
+            // atomics, and several descendants of the level may hit the same entry of an ancestor at once, in an order
+            // that differs from run to run (last bits of L).  Here the updates of the level are dealt into ROUNDS: round
+            // r holds, for every ancestor, the r-th of the level's descendants that update it (descendants in index
+            // order).  Inside a round every entry of Lx receives at most one addition (one task per target panel; the
+            // relative map of a pair is injective), the rounds are launched one after the other, so every entry sees
+            // its additions in one fixed order and two runs give identical bits -- as the reference's sequential loop
+            // over the descendants does (t_cholmod_super_numeric_worker.c:588-967).  Cost: as many launch groups per
+            // level as the busiest ancestor has descendants on it.
+            std::stable_sort(ls.updates.begin(), ls.updates.end(), [](const GemmTask &a, const GemmTask &b) {
+                return a.c_off != b.c_off ? a.c_off < b.c_off : a.a_off < b.a_off; });   // (a_off grows with the descendant)
+            std::vector<std::vector<GemmTask>> rounds;
+            size_t r = 0;
+            for (size_t k = 0; k < ls.updates.size(); k++) {
+                r = (k > 0 && ls.updates[k].c_off == ls.updates[k - 1].c_off) ? r + 1 : 0;
+                if (rounds.size() <= r) rounds.resize(r + 1);
+                rounds[r].push_back(ls.updates[k]);
+            }
+            for (auto &rd : rounds) flush_gemm(out, rd, lev, S, 0, STEP_JOIN);
+        } else
         flush_gemm(out, ls.updates, lev, S, 0, STEP_JOIN);
     }
 }

@@ -1010,14 +1010,14 @@ __device__ __forceinline__ double keep_if(double v, bool keep)
     return v;
 }
 
-template <int E, int KB, int NT>
+template <int E, int KB, int NT, int NJB = 4 * E>
 __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrr, int j0)
 {
-    constexpr int NJ = 64 * E;            // real columns of Y per pass
-    constexpr int NJB = NJ / 16;
+    constexpr int NJ = 16 * NJB;          // real columns of Y per pass: 64 E (all of 64 right-hand sides), or 16 for a few
+                                          // right-hand sides (NJB = 1: an eighth of the products and of the LDS image)
     constexpr int LD = KB * 64 + 2;       // LDS row stride: 16 j x 2 k of a half-wave on 32 disjoint bank pairs
     constexpr int QC = 16 / E;            // k-steps (of 4 columns) per chunk of the operand ring
     constexpr int NW = NT / 64;
@@ -1156,21 +1156,24 @@ __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     }
 }
 
-template <int E, int KB>
+template <int E, int KB, int NJB = 4 * E>
 __global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
     const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
     int nrr, int j0)
 {
-    constexpr int NJ = 64 * E;            // real columns of Y per pass
-    constexpr int NJB = NJ / 16;
+    constexpr int NJ = 16 * NJB;          // real columns of Y per pass: 64 E, or 16 for a few right-hand sides (NJB = 1)
     constexpr int RT = 64 / E;            // rows per tile step (the same bytes of L per step, real and complex)
     constexpr int LDT = RT + 2;
     constexpr int NQ = RT / 4;            // k-steps per tile
     constexpr int NW = WIDE_THREADS / 64;
-    constexpr int JW = NJB / 2;           // j-blocks per wave
+    constexpr int JW = NJB >= 2 ? NJB / 2 : 1;       // j-blocks per wave
+    // the 8 waves: 4 column blocks x 2 halves of the j-blocks -- or, with one j-block, x 2 halves of the tile's rows (both
+    // halves add their partial sums into x1 at the end)
+    constexpr int QH = NJB >= 2 ? NQ : NQ / 2;       // k-steps per wave and tile
+    constexpr int NYT = (NJ * RT + WIDE_THREADS - 1) / WIDE_THREADS;
     constexpr int NL = 64 * RT * E / WIDE_THREADS;   // doubles of an L block per thread (8)
-    constexpr int NY = NJ * RT / WIDE_THREADS;       // entries of the gathered rows of Y per thread (8)
+    constexpr int NY = NYT;                          // entries of the gathered rows of Y per thread (8; 2 with NJB = 1)
     __shared__ double Xt[2][NJ][LDT];     // Xt[.][j][r]
     __shared__ double Lt[2][E][64][LDT];  // Lt[.][re/im][c][r]
     __shared__ int32_t rows_s[WIDE_MAX_RUN * 64];   // rows of Y the run gathers
@@ -1230,6 +1233,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
 #pragma unroll
         for (int i = 0; i < NY; i++) {
             const int u = w + NW * i, j = 16 * (u % NJB) + l15, r = ti * RT + 4 * (u / NJB) + l4;
+            static_assert(NW * NY == (RT / 4) * NJB, "the units of a tile's rows of Y divide evenly over the waves");
             yreg[i] = Y[(int64_t)rows_s[min(r, rows_run - 1)] * ldr + j0 + min(j, nj - 1)];
         }
     };
@@ -1263,10 +1267,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
             if (b == 0) load_Y(tn);
             load_L(lreg[b & 1], min(ti + (b + 2) / KB, ntile - 1), (b + 2) % KB);
             if (64 * b < ncols) {                                 // uniform; no memory requests inside
-                const double *__restrict__ la = &Lt[b & 1][0][16 * cb + l15][l4];
-                const double *__restrict__ xa = &Xt[ti & 1][16 * JW * jh + l15][l4];
+                const int qoff = (NJB >= 2) ? 0 : 4 * QH * jh;        // one j-block: wave half jh takes the k-steps [QH jh, QH jh + QH)
+                const double *__restrict__ la = &Lt[b & 1][0][16 * cb + l15][l4 + qoff];
+                const double *__restrict__ xa = &Xt[ti & 1][(NJB >= 2 ? 16 * JW * jh : 0) + l15][l4 + qoff];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
+                for (int q = 0; q < QH; q++) {
                     const double ar = la[4 * q];
                     double ai = 0.0;
                     if constexpr (E == 2) ai = la[64 * LDT + 4 * q];
@@ -1291,7 +1296,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
         for (int jj = 0; jj < JW; jj++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int c = 64 * b + 16 * cb + l4 + 4 * g, jo = 16 * (JW * jh + jj);
+                const int c = 64 * b + 16 * cb + l4 + 4 * g, jo = (NJB >= 2) ? 16 * (JW * jh + jj) : 0;
                 double v = P[b][jj][g];
                 if constexpr (E == 2) {
                     const double qx = __shfl_xor(Q[b][jj][g], 1, 64);        // every lane takes part

@@ -233,6 +233,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 13) tuning().solve_bwd_div_mma = value;
     else if (key == 14) tuning().tiny_max = value;
     else if (key == 26) tuning().fuse_potrf = value;
+    else if (key == 27) tuning().deterministic = value;
     else if (key == 100) hostrun::use_device_source = value;    // run the product's host-runnable kernels
 }
 

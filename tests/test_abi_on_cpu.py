@@ -531,3 +531,11 @@ def test_copy_lanes_are_sized_by_the_factor(engine):
         assert 0 < pinned <= max(most, 2 * fbytes), (name, pinned, fbytes)
         L.close()
         assert emu.hipcpu_pinned_bytes() == base
+
+
+@pytest.mark.parametrize("name", ["lap3d_8_metis", "helm3d_6_metis", "tcov_c30lo_singular"])
+def test_deterministic_mode_through_the_abi(engine, name):
+    """tuning key 27 (rounds of scatter updates): the schedule it builds gives the reference's factor (the CPU build runs
+    workgroups one after the other, so identical bits are no news here; the GPU test of the same name is the real one)"""
+    import test_gpu_parity as tp
+    tp.test_deterministic_mode_gives_identical_bits(engine, name)

@@ -900,3 +900,32 @@ def test_numeric_host_copies_under_the_factorization(engine, name, chunk):
         L.close()
     finally:
         engine.set_tuning(18, 32 << 20)
+
+
+@pytest.mark.parametrize("name", ["lap3d_8_metis", "elast27_4_metis", "lap2d_16_metis", "helm3d_6_metis", "tcov_c30lo_singular"])
+def test_deterministic_mode_gives_identical_bits(engine, name):
+    """tuning key 27: the scatter updates of a level run in rounds of at most one descendant per ancestor, so every entry
+    of L receives its additions in one fixed order -- three factorizations of the same matrix (plain, again, and with the
+    copy to the host under the factorization) are equal BIT FOR BIT, as two runs of the reference are; and the factor is
+    still the reference's to 1e-10.  (Without the key the FP64 atomics of concurrent descendants arrive in any order.)"""
+    from conftest import load_golden, sym_of
+    g = load_golden(name)
+    cplx = g["xtype"] == 2
+    engine.set_tuning(27, 1)
+    try:
+        L = engine.SupernodalFactor(sym_of(g), xtype=2 if cplx else 1)
+        L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+        st = L.numeric(beta=g["beta"])
+        first = L.Lx().copy()
+        assert st == g["status"] and L.minor == g["minor"]
+        L.numeric(beta=g["beta"] + 0.5)                     # something else in between
+        assert L.numeric(beta=g["beta"]) == st
+        second = L.Lx().copy()
+        st3, third = L.numeric_host(beta=g["beta"])
+        assert st3 == st
+        assert np.array_equal(first.view(np.uint64), second.view(np.uint64))
+        assert np.array_equal(first.view(np.uint64), np.ascontiguousarray(third).view(np.uint64))
+        assert np.array_equal(first == 0, g["Lx"] == 0) and relerr(first, g["Lx"]) < TOL_L
+        L.close()
+    finally:
+        engine.set_tuning(27, 0)

@@ -88,6 +88,37 @@ def main():
                   f"top with look-ahead ({cnt['lookahead_bcasts']} of {cnt['top_blocks']} broadcasts have launches behind them) {top2 * 1e3:.0f} ms "
                   f"-> {total2 * 1e3:.0f} ms  speedup {t1 / total2:.2f}, efficiency {t1 / total2 / world:.2f}, "
                   f"{sym['fl'] / total2 / world / 78.6e12 * 100:.0f} % of {world} x 78.6 TF")
+            # (ii b) the reduce channel (tuning key 19, built in round 2, default off until it has run on xGMI): the sums
+            # of the top supernodes ABOVE the lowest top level travel on a communicator and stream of their own while
+            # the lowest top level -- whose ranges must have arrived first -- runs its panel phase (chains + inner and
+            # outer trailing updates of those supernodes; their scatter updates into the higher top supernodes come at
+            # the end of the level and wait for the sums).  Hidden = min(time of that panel phase, volume above / rate).
+            lev = np.zeros(sym["nsuper"], dtype=np.int64)
+            Super, Lpi, Ls = sym["Super"], sym["Lpi"], sym["Ls"]
+            colmap = np.repeat(np.arange(sym["nsuper"]), np.diff(Super))
+            nscol = np.diff(Super).astype(float); nsrow = np.diff(Lpi).astype(float)
+            for s_ in range(sym["nsuper"]):
+                if nsrow[s_] > nscol[s_]:
+                    par = colmap[Ls[Lpi[s_] + int(nscol[s_])]]
+                    lev[par] = max(lev[par], lev[s_] + 1)
+            top_s = np.nonzero(owner < 0)[0]
+            if len(top_s):
+                lo_lev = lev[top_s].min()
+                low = top_s[lev[top_s] == lo_lev]
+                high = top_s[lev[top_s] > lo_lev]
+                vol_high = float((nsrow[high] * nscol[high]).sum()) * 8
+                below = nsrow[low] - nscol[low]
+                # panel phase of the lowest top level: dense partial factorization of its supernodes, shared by the owners
+                fl_low = float((nscol[low] ** 3 / 3 + below * nscol[low] ** 2).sum())
+                chain_low = float((np.ceil(nscol[low] / 64)).max()) * STEP_US * 1e-6
+                t_low = fl_low / world / (GEMM_TFLOPS * 1e12) + chain_low
+                t_high = vol_high * (world - 1) / world / (XGMI_GBS * 1e9)
+                hid = min(t_low, t_high, red2)
+                total3 = total2 - hid
+                print(f"      model (round 2 schedule + reduce channel, key 19): lowest top level = {len(low)} supernodes (panel phase {t_low * 1e3:.0f} ms), "
+                      f"{vol_high * 1e-9:.1f} of {top_entries * 8e-9:.1f} GB of sums belong to the levels above it ({t_high * 1e3:.0f} ms) -> {hid * 1e3:.0f} ms of the "
+                      f"reduction hidden -> {total3 * 1e3:.0f} ms  speedup {t1 / total3:.2f}, efficiency {t1 / total3 / world:.2f}, "
+                      f"{sym['fl'] / total3 / world / 78.6e12 * 100:.0f} % of {world} x 78.6 TF")
             # (iii) pieces (tuning key 17): what still has to travel when a block's chain ends is its last piece only; the
             # chain -> broadcast -> update of the next block -> next chain path of the top carries that, not the whole block
             tail = bcast * (cnt["top_blocks"] - cnt["top_pieces"]) / max(cnt["top_blocks"], 1)

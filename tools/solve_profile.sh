@@ -2,11 +2,13 @@
 # kernel trace of one forward+backward solve at 150^3 (nrhs = $1, default 1)
 set -e
 NR=${1:-1}
+PROB=${2:-lap3d}
+GRID=${3:-150}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_solve_$NR
+O=$R/gpurun_out/prof_solve_${2:-lap3d}_$NR
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace -d $O -o s -- python3 $R/bench.py --grid 150 --steps 1 --warmup 0 --no-cpu --solve --nrhs $NR > $O/bench.json 2> $O/err.txt
+timeout -s KILL 300 rocprofv3 --kernel-trace -d $O -o s -- python3 $R/bench.py --problem $PROB --grid $GRID --steps 1 --warmup 0 --no-cpu --solve --nrhs $NR > $O/bench.json 2> $O/err.txt
 python3 - $O/s_results.db <<'PY'
 # per kernel: launches, total, mean, and the same by grid size; then the gaps between consecutive solve kernels
 import sqlite3, sys
