@@ -70,7 +70,7 @@ def analyze(p, ordering="nd"):
     return sym, (Sp, Si, Sx), time.time() - t
 
 
-def cpu_baseline(kind, grid, ordering="nd"):
+def cpu_baseline(kind, grid, ordering="nd", full_grid=None, full_fl=None, full_xsize=None):
     """reference CPU supernodal numeric (cholmod_l_super_numeric, host BLAS) on a bounded sample"""
     try:
         from oracle import refcholmod
@@ -112,7 +112,12 @@ def cpu_baseline(kind, grid, ordering="nd"):
                 "L_ordering": inf["ordering_name"], "fl": inf["fl"], "factor_s": round(best, 3),
                 "sample": f"{name}, same {'METIS' if ordering == 'metis' else 'nested-dissection'} ordering, fl={inf['fl']:.4g}, "
                           f"reference cholmod_l_super_numeric + MKL, best of {reps} = {best:.3f} s; "
-                          f"cholmod_l_super_lsolve + _ltsolve, nrhs 1, best of 2 = {tsolve * 1e3:.1f} ms"}
+                          f"cholmod_l_super_lsolve + _ltsolve, nrhs 1, best of 2 = {tsolve * 1e3:.1f} ms"
+                          + (f"; a bounded sample, not the bench workload (grid {full_grid}): at this rate the reference "
+                             f"would need about {full_fl / (inf['fl'] / best):.0f} s per factorization of the full size on these "
+                             f"cores (fl {full_fl:.3g}, a factor of {full_xsize * 8e-9:.0f} GB on the host), beyond the few "
+                             f"minutes a default run may take"
+                             if full_grid is not None and full_grid != grid and full_fl and full_xsize else "")}
     except Exception as e:      # noqa: BLE001
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
 
@@ -342,7 +347,8 @@ def main():
                 pass
             # bounded sample, ~10-40 s of host work: lap3d 100^3 is fl 6.3e12 (8 GB of host factor)
             cg = args.cpu_grid or {"lap3d": 100, "lap2d": 2000, "elast": 48, "helm": 64}[args.problem]
-            out["cpu_baseline"] = cpu_baseline(args.problem, min(cg, grid), args.ordering)
+            out["cpu_baseline"] = cpu_baseline(args.problem, min(cg, grid), args.ordering, full_grid=grid, full_fl=float(sym["fl"]),
+                                              full_xsize=int(sym["xsize"]) * (2 if np.iscomplexobj(p["Ax"]) else 1))
         else:
             out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only"}

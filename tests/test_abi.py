@@ -88,3 +88,32 @@ def test_cholmod_side_glue_exports_its_header():
     for h in hooks:
         assert h in defined, h
     assert undefined and undefined <= set(declared_symbols()), undefined - set(declared_symbols())
+
+
+def test_rccl_declarations_match_the_installed_header():
+    """multi.hip.hpp declares the slice of rccl.h it binds with dlsym by hand; the installed header must agree (enum
+    values, the 128-byte id passed by value, every signature), or the first run on several GPUs would be the check."""
+    import re
+    import shutil
+    import subprocess
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr) or shutil.which("g++") is None:
+        pytest.skip("no rccl.h / g++ on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "suitesparse_amd", "csrc", "multi.hip.hpp")).read()
+    m = re.search(r"constexpr int RCCL_F64 = (\d+), RCCL_I64 = (\d+), RCCL_SUM = (\d+), RCCL_MIN = (\d+);", src)
+    assert m, "the constants of multi.hip.hpp moved"
+    assert "struct RcclId { char internal[128]; };" in src
+    # the pointer types the engine declares, spelled with ints and void * (what the check file spells with rccl's types)
+    for decl in ["int (*GetUniqueId)(RcclId *)", "int (*CommInitRank)(void **, int, RcclId, int)", "int (*CommDestroy)(void *)",
+                 "int (*CommSplit)(void *, int, int, void **, void *)",
+                 "int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t)",
+                 "int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t)",
+                 "int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t)",
+                 "int (*GroupStart)()", "int (*GroupEnd)()", "const char *(*GetErrorString)(int)"]:
+        assert decl in src, decl
+    f64, i64, s_, mn = m.groups()
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        f"-DF64={f64}", f"-DI64={i64}", f"-DSUM={s_}", f"-DMIN={mn}",
+                        os.path.join(root, "tests", "helpers", "rccl_abi_check.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

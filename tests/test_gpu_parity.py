@@ -459,27 +459,41 @@ def test_full_size_properties(engine, grid):
     assert float((X2 - Y0).abs().max()) < 1e-9 * float(Y0.abs().max())
 
 
-def _named_problem(kind, grid):
+def _named_problem(kind, grid, ordering="nd"):
     from suitesparse_amd import problems, symbolic
     p = {"lap2d": problems.laplacian_2d, "lap3d": problems.laplacian_3d, "elast": problems.elasticity27,
          "helm": problems.helmholtz_3d}[kind](grid)
-    perm = symbolic.nd_grid_order(p["shape"], p["dof"])
+    if ordering == "metis":
+        # the permutation the reference's own analysis picks (cholmod_l_analyze with CHOLMOD_METIS,
+        # CHOLMOD/Cholesky/cholmod_analyze.c:629-684): the structure CHOLMOD would hand to the engine
+        from oracle import refcholmod
+        r = refcholmod.RefCholmod()
+        r.load(p["n"], p["Ap"], p["Ai"], p["Ax"], -1)
+        r.analyze(ordering="metis")
+        perm = r.symbolic()["Perm"]
+        r.close()
+    else:
+        perm = symbolic.nd_grid_order(p["shape"], p["dof"])
     sym = symbolic.analyze(p["n"], p["Ap"], p["Ai"], perm)
     Sp, Si, Sx = symbolic.permute(sym, p["Ap"], p["Ai"], p["Ax"])
     return p, sym, Sp, Si, Sx
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("kind,grid,nrhs", [("lap2d", 2000, 3), ("elast", 80, 3), ("helm", 100, 64)])
-def test_full_size_properties_of_the_other_configs(engine, kind, grid, nrhs):
-    """BASELINE configs 2, 4 and 5 at their stated sizes (2D 2000^2; 27-point 3-dof 80^3; complex Hermitian Helmholtz
+@pytest.mark.parametrize("kind,grid,nrhs,ordering", [("lap2d", 2000, 3, "nd"), ("elast", 80, 3, "nd"), ("helm", 100, 64, "nd"),
+                                                     ("lap2d", 2000, 3, "metis")])
+def test_full_size_properties_of_the_other_configs(engine, kind, grid, nrhs, ordering, have_ref):
+    """BASELINE configs 2, 4 and 5 at their stated sizes (2D 2000^2 -- on the geometric ordering and, as the config
+    states it, on the reference's METIS ordering; 27-point 3-dof 80^3; complex Hermitian Helmholtz
     100^3 with 64 right-hand sides), checked through size-independent properties: the backward error
     ||A x - b||_inf / (||A||_inf ||x||_inf + ||b||_inf) of every column at rounding level, b = A*1 solves back to 1,
     the solve is linear (last column = a combination of the first two), and a refactorization reproduces the
     solution to the atomics' summation-order noise."""
     import scipy.sparse as sp
     import torch
-    p, sym, Sp, Si, Sx = _named_problem(kind, grid)
+    if ordering == "metis" and not have_ref:
+        pytest.skip("oracle/_ref (the reference's METIS) not built")
+    p, sym, Sp, Si, Sx = _named_problem(kind, grid, ordering)
     n = p["n"]
     cplx = np.iscomplexobj(Sx)
     S = sp.csc_matrix((Sx, Si, Sp), shape=(n, n))
