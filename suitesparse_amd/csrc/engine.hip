@@ -80,6 +80,8 @@ struct DeviceSchedule {
     DevBuf<GemmTask> gemm;
     DevBuf<PotrfTask> potrf;
     DevBuf<int32_t> potrf_order;        // Schedule::potrf_order (empty unless the tiny classes are on)
+    DevBuf<PanelGroup> pgroups;         // Schedule::pgroups / pg_wg_task (panel groups, Tuning::panel_group)
+    DevBuf<int32_t> pg_wg_task;
     DevBuf<int32_t> relmap, solve_tmap;
     DevBuf<Schedule::TileEntry> gemm_tmap;
     // grouped solve sweep (built on first use)
@@ -203,6 +205,8 @@ int upload_schedule(mi355_factor_s *F, DeviceSchedule &D)
     HIP_TRY(D.gemm.upload(S.gemm.data(), S.gemm.size(), F->stream));
     HIP_TRY(D.potrf.upload(S.potrf.data(), S.potrf.size(), F->stream));
     if (!S.potrf_order.empty()) HIP_TRY(D.potrf_order.upload(S.potrf_order.data(), S.potrf_order.size(), F->stream));
+    if (!S.pgroups.empty()) HIP_TRY(D.pgroups.upload(S.pgroups.data(), S.pgroups.size(), F->stream));
+    if (!S.pg_wg_task.empty()) HIP_TRY(D.pg_wg_task.upload(S.pg_wg_task.data(), S.pg_wg_task.size(), F->stream));
     HIP_TRY(D.gemm_tmap.upload(S.gemm_tile_tab.data(), S.gemm_tile_tab.size(), F->stream));
     HIP_TRY(D.solve_tmap.upload(S.solve_tile_task.data(), S.solve_tile_task.size(), F->stream));
     HIP_TRY(D.relmap.alloc((size_t)S.relmap_size));
@@ -558,6 +562,30 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
                                    D.potrf.p + st.first, F->Lx.p, F->Dinv.p, F->info.p, (const int32_t *)nullptr);
             tm.end(1);
             if (st.count > st.nfused) F->st_npotrf += 1;
+        } else if (st.kind == STEP_PDIAG) {
+            // panel groups: the diagonal windows (<= 256 columns each), one workgroup per window
+            if (cplx || st.count > 0x7fffffffLL) return fail(MI355_GPU_PROBLEM, "internal: panel group step");
+            tm.begin(1);
+            hipLaunchKernelGGL(k_panel_diag, dim3((unsigned)st.count), dim3(256), 0, F->stream,
+                               (const PanelGroup *)(D.pgroups.p + st.first), F->Lx.p, F->Dinv.p, F->info.p);
+            tm.end(1);
+            F->st_npotrf += 1;
+        } else if (st.kind == STEP_PTRSM) {
+            // ... and the rows below them, ROWS rows of a panel per workgroup through the whole window
+            if (cplx || st.ntiles > 0x7fffffffLL) return fail(MI355_GPU_PROBLEM, "internal: panel group step");
+            tm.begin(0);
+            const PanelGroup *pg = D.pgroups.p + st.first;
+            const int32_t *wt = D.pg_wg_task.p + st.tmap_off;
+            if (st.ngrouped == 128)
+                hipLaunchKernelGGL(k_panel_trsm_reg<8>, dim3((unsigned)st.ntiles), dim3(512), 0, F->stream, pg, wt, (const double *)F->Dinv.p, F->Lx.p);
+            else if (st.ngrouped == 64)
+                hipLaunchKernelGGL(k_panel_trsm_reg<4>, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream, pg, wt, (const double *)F->Dinv.p, F->Lx.p);
+            else if (st.ngrouped == 32)
+                hipLaunchKernelGGL(k_panel_trsm<32>, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream, pg, wt, (const double *)F->Dinv.p, F->Lx.p);
+            else
+                hipLaunchKernelGGL(k_panel_trsm<16>, dim3((unsigned)st.ntiles), dim3(256), 0, F->stream, pg, wt, (const double *)F->Dinv.p, F->Lx.p);
+            tm.end(0);
+            F->st_ngemm += 1;
         } else {
             if (st.ntiles > 0x7fffffffLL || st.count > 0x7fffffffLL)
                 return fail(MI355_TOO_LARGE, "too many GEMM tiles in one step");
@@ -597,6 +625,9 @@ int run_schedule(mi355_factor_s *F, DeviceSchedule &D, int64_t ncols_asm, double
             (void)hipEventElapsedTime(&ms, le0, le1);
             if (st.kind == STEP_POTRF) {
                 fprintf(steplog, "potrf level %d count %lld ms %.4f\n", st.level, (long long)st.count, ms);
+            } else if (st.kind == STEP_PDIAG || st.kind == STEP_PTRSM) {
+                fprintf(steplog, "%s level %d count %lld ntiles %lld ms %.4f\n", st.kind == STEP_PDIAG ? "pdiag" : "ptrsm", st.level,
+                        (long long)st.count, (long long)st.ntiles, ms);
             } else {
                 double fl = 0, xfl = 0; int kmin = 1 << 30, kmax = 0; int64_t mmax = 0, nmax = 0;
                 for (int64_t i = 0; i < st.count; i++) {
@@ -749,6 +780,7 @@ int mi355_factor_create_limited(int xtype, int64_t n, int64_t nsuper, const int6
             + 24.0 * (double)(nsuper + 1) + 4.0 * (double)(nsuper + 2)
             + (double)sizeof(GemmTask) * sc.gemm.size() + (double)sizeof(PotrfTask) * sc.potrf.size()
             + 4.0 * sc.potrf_order.size() + (double)sizeof(Schedule::TileEntry) * sc.gemm_tile_tab.size()
+            + (double)sizeof(PanelGroup) * sc.pgroups.size() + 4.0 * sc.pg_wg_task.size()
             + 4.0 * sc.solve_tile_task.size() + 4.0 * (double)sc.relmap_size + (double)sizeof(RelmapPair) * sc.pairs.size();
         if (needed_bytes) *needed_bytes = (int64_t)need;
         size_t fr = 0, tot = 0;
@@ -1080,6 +1112,10 @@ int mi355_factor_host_copy_plan(mi355_factor *F, int64_t cap, int64_t *plan, int
             if (st.kind == STEP_POTRF) {
                 const double nb = sc.potrf[(size_t)ti].nb;
                 fl += nb * nb * nb / 3.0;
+            } else if (st.kind == STEP_PDIAG || st.kind == STEP_PTRSM) {
+                const PanelGroup &g = sc.pgroups[(size_t)ti];
+                const double nc = g.ncols;
+                fl += st.kind == STEP_PDIAG ? nc * nc * nc / 3.0 : (double)g.below * nc * nc;
             } else {
                 const GemmTask &t = sc.gemm[(size_t)ti];
                 const double Mm = t.M, Nn = t.N, Kk = t.K;
@@ -2142,6 +2178,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 25) tuning().solve_wide_1024 = value ? 1 : 0;
     else if (key == 26) tuning().fuse_potrf = value ? 1 : 0;
     else if (key == 27) tuning().deterministic = value ? 1 : 0;
+    else if (key == 28) tuning().panel_group = std::max(0, value);
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

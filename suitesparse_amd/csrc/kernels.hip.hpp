@@ -735,6 +735,9 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane)      // srcl
 // The work of one workgroup (256 threads) on one block; Ls / Vs: two LDS images of NB x (NB + 1) doubles.
 // FRESH: the block was written by THIS workgroup a moment ago (k_gemm128's fused call: its read-modify-write stores,
 // made visible by a fence and a barrier): the loads bypass the vector L1, whose lines may predate those stores.
+__device__ __forceinline__ void potrf64_core(
+    const PotrfTask &t, double *Lx, double *Dinv, int *info, double (*Ls)[NB + 1], double (*Vs)[NB + 1]);
+
 template <bool FRESH>
 __device__ __forceinline__ void potrf64_block(
     const PotrfTask &t, double *Lx, double *Dinv, int *info, double (*Ls)[NB + 1], double (*Vs)[NB + 1])
@@ -758,7 +761,19 @@ __device__ __forceinline__ void potrf64_block(
         Vs[i][j] = 0.0;
     }
     __syncthreads();
+    potrf64_core(t, Lx, Dinv, info, Ls, Vs);
+}
 
+// ... and the factorization proper: Ls holds the block (row i, column j; identity beyond nb up to the next multiple of 16),
+// Vs zeros; on return Ls = L, Vs = inv(L), both also written to Lx / Dinv.
+__device__ __forceinline__ void potrf64_core(
+    const PotrfTask &t, double *Lx, double *Dinv, int *info, double (*Ls)[NB + 1], double (*Vs)[NB + 1])
+{
+    const int tid = threadIdx.x;
+    const int nb = t.nb;
+    const int64_t lda = t.lda;
+    double *A = Lx + t.a_off;
+    const int nblk = (nb + 15) >> 4;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     int fail_col = 0;                                         // wave 0 only: 1-based column of the first bad pivot
 #pragma unroll 1
@@ -873,6 +888,181 @@ __global__ __launch_bounds__(256) void k_potrf64(
     __shared__ double Vs[NB][NB + 1];       // its inverse
     const PotrfTask t = tasks[order ? order[blockIdx.x] : (int)blockIdx.x];
     potrf64_block<false>(t, Lx, Dinv, info, Ls, Vs);
+}
+
+//------------------------------------------------------------------------------
+// k_panel_diag (STEP_PDIAG): the diagonal window of a panel group -- ncols x ncols, 64 < ncols <= 256, lower -- factorized
+// by ONE workgroup, left-looking over its 64-column blocks.  It is a pure latency chain (277 of them in a row make the
+// panel chain of the 150^3 root), so every value stays where the next step needs it:
+//  * a wave owns up to four 16-row strips of block column b (rows from the diagonal block down) and holds them in
+//    registers in MFMA RESULT layout -- which is also the operand layout of the next product -- from their load to their
+//    last use;
+//  * the updates by the block columns before b (T -= L(:, k) L(b, k)^T) take their 64 x 64 operand block through LDS,
+//    one block per barrier pair, and accumulate straight into those registers;
+//  * the diagonal block goes from the registers into the LDS image that potrf64_core factorizes (no trip through
+//    memory), and the strips below it are multiplied by the inverse that the factorization leaves in LDS (X = T W^T),
+//    again from the registers, and stored once.
+// Four launches of k_potrf64, four of k_trsm64 and three trailing updates on these rows become one launch; the rows BELOW
+// the window follow in k_panel_trsm_reg.  What one phase stores the next one loads after a barrier (one workgroup = one
+// CU = one vector L1, written through).
+//------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_panel_diag(
+    const PanelGroup *__restrict__ groups, double *Lx, double *Dinv, int *info)
+{
+    // one LDS image of up to 192 rows x 64 columns: during the updates the rows of a block column from the diagonal block
+    // down; for the factorization its first 64 rows are the block (Ls) and the next 64 its inverse (Vs)
+    __shared__ double P[3 * NB][NB + 1];
+    double (*Ls)[NB + 1] = P;
+    double (*Vs)[NB + 1] = P + NB;
+    const PanelGroup g = groups[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ncols = g.ncols, nblk = (ncols + NB - 1) / NB;
+    const int64_t lda = g.lda;
+    double *A = Lx + g.a_off;                                   // A[i + j * lda]: row i, column j of the window
+    const uint32_t l4off = (uint32_t)l4 * (uint32_t)lda;        // (lda < 2^27 for a panel group: 32-bit lane offsets)
+#pragma unroll 1
+    for (int b = 0; b < nblk; b++) {
+        const int c0 = NB * b, nbb = min(NB, ncols - c0);
+        const int nstrips = (ncols - c0 + 15) >> 4;             // 16-row strips from row c0 down; 0 .. 3 are the diagonal block
+        // this wave's strips: w (diagonal block), w + 4, w + 8, w + 12; lane % 16 = row of the strip
+        uint32_t roff[4];
+        bool live[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = c0 + 16 * (w + 4 * i) + l15;
+            live[i] = w + 4 * i < nstrips;                      // uniform over the wave
+            roff[i] = (uint32_t)min(r, ncols - 1) + l4off;      // (clamped rows are loaded, never stored)
+        }
+        // T in result layout: t[i][cb][gq] = entry (row of strip i, column c0 + 16 cb + lane / 16 + 4 gq)
+        v4d t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) {
+                t[i][cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+                if (live[i] && (i == 0 || b > 0))               // (block column 0 has no updates: its lower strips are loaded after the factorization)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int n0 = 16 * cb + 4 * gq;            // column of lane group 0; uniform
+                    if (nbb == NB) t[i][cb][gq] = (A + (int64_t)(c0 + n0) * lda)[roff[i]];
+                    else {
+                        // the last, narrower block of a window: no column beyond it is touched
+                        const int n = n0 + l4;
+                        const double v = A[(roff[i] - l4off) + (int64_t)(c0 + min(n, nbb - 1)) * lda];
+                        t[i][cb][gq] = n < nbb ? v : 0.0;
+                    }
+                }
+            }
+        // ---- updates by the block columns before b, 64 columns of the contraction per round
+#pragma unroll 1
+        for (int kc = 0; kc < b; kc++) {
+            // rows c0 .. ncols - 1 of block column kc -> P[n][k] (thread: n = tid % 64 + 64 j, k = tid / 64 + 4 i); the first
+            // 64 rows are the operand block L(b, kc) of every product, each strip finds its own rows further down
+            {
+                const int nrow = ncols - c0;
+                double sreg[3][16];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t voff = (uint32_t)min((tid & 63) + NB * j, nrow - 1) + (uint32_t)(tid >> 6) * (uint32_t)lda;
+                    if (NB * j < nrow) {                        // uniform  (no break / continue in these loops: a loop that is
+                                                                // not unrolled early leaves its register arrays in scratch)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) sreg[j][i] = (A + c0 + (int64_t)(NB * kc + 4 * i) * lda)[voff];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const bool in = (tid & 63) + NB * j < nrow;
+                    if (NB * j < nrow) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) P[(tid & 63) + NB * j][(tid >> 6) + 4 * i] = in ? sreg[j][i] : 0.0;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (live[i]) {
+                    double a[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) a[q] = -P[16 * (w + 4 * i) + l15][4 * q + l4];
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+#pragma unroll
+                        for (int cb = 0; cb < 4; cb++)
+                            t[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[16 * cb + l15][4 * q + l4], a[q], t[i][cb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the diagonal block: registers -> the LDS image (identity beyond nbb), factorized and inverted there
+        {
+            const int i_ = 16 * w + l15;
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int j = 16 * cb + l4 + 4 * gq;
+                    double v = (i_ == j) ? 1.0 : 0.0;
+                    if (i_ < nbb && j < nbb) v = (i_ >= j) ? t[0][cb][gq] : 0.0;
+                    Ls[i_][j] = v;
+                    Vs[i_][j] = 0.0;
+                }
+        }
+        // the updated strips below the diagonal block go back to memory (they would have to stay in registers across the
+        // factorization: 96 of them, next to its own hundred) and return as operands afterwards
+        if (b > 0) {
+#pragma unroll
+            for (int i = 1; i < 4; i++) {
+                if (live[i] && c0 + 16 * (w + 4 * i) + l15 < ncols) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) (A + (int64_t)(c0 + 16 * cb + 4 * gq) * lda)[roff[i]] = t[i][cb][gq];   // (a block with rows below it is full)
+                }
+            }
+        }
+        __syncthreads();
+        PotrfTask pt;
+        pt.a_off = g.a_off + c0 + (int64_t)c0 * lda; pt.dinv_off = groups[blockIdx.x].dinv_off[b]; pt.ls_off = 0; pt.stile0 = 0;   // (in place: g indexed by b would live in scratch)
+        pt.lda = g.lda; pt.nb = nbb; pt.s = g.s; pt.col0 = g.col0 + c0; pt.k1 = 0; pt.nscol = 0; pt.urow0 = 0; pt.fuse_trsm = 0;
+        potrf64_core(pt, Lx, Dinv, info, Ls, Vs);
+        // ---- the strips below it: X = T * W^T (W = Vs, lower; the result registers of T are the operand registers here)
+        if (b + 1 < nblk) {
+            const int nq = (nbb + 3) >> 2, ncb = (nbb + 15) >> 4;
+#pragma unroll
+            for (int i = 1; i < 4; i++) {
+                if (live[i]) {
+                v4d x[4];
+                double a[16];
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) x[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 16; q++) a[q] = (A + (int64_t)(c0 + 4 * q) * lda)[roff[i]];   // operand layout: column 4 q + lane / 16
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) {
+                        if (q > 4 * cb + 3) continue;            // above W's diagonal
+                        if (q < nq && cb < ncb)                  // (uniform) inside the block
+                            x[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[16 * cb + l15][4 * q + l4], a[q], x[cb], 0, 0, 0);
+                    }
+                }
+                const int r = c0 + 16 * (w + 4 * i) + l15;
+                if (r < ncols) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) {
+                            const int n = 16 * cb + l4 + 4 * gq;
+                            if (n < nbb) A[r + (int64_t)(c0 + n) * lda] = x[cb][gq];
+                        }
+                }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 //------------------------------------------------------------------------------

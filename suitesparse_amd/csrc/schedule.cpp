@@ -3,6 +3,7 @@
 #include <cmath>
 #include <algorithm>
 #include <unordered_map>
+#include <unordered_set>
 #include <cstdio>
 
 namespace mi355 {
@@ -79,10 +80,14 @@ struct LevelSteps {
     // DistTop: is potrf[it][i] (and its trsm task) this rank's; blocks that complete at iteration it
     std::vector<std::vector<int8_t>> mine;
     std::vector<std::vector<BcastPoint>> bcast;
+    // panel groups that START at iteration it; blk[b] = position of the group's b-th block in potrf[it + b]
+    struct Group { PanelGroup g; size_t blk[4]; };
+    std::vector<std::vector<Group>> pgroup;
     void ensure(size_t it)
     {
         if (potrf.size() <= it) {
             potrf.resize(it + 1); trsm.resize(it + 1); trail.resize(it + 1); rest.resize(it + 1); mine.resize(it + 1); bcast.resize(it + 1);
+            pgroup.resize(it + 1);
         }
     }
 };
@@ -266,6 +271,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     out.nlevels = nlev;
 
     std::vector<LevelSteps> L(nlev);
+    std::unordered_set<int64_t> grouped_blocks;     // diagonal blocks (offset in Lx) that a panel group factorizes
 
     // DistTop: owner of outer block jb of masked supernode s = (position of s among the masked supernodes of
     // its level + jb * their number + level) mod world -- blocks that are worked on at the same time (same
@@ -318,14 +324,34 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             const int64_t w3 = (tuning().ob3 / NB) * NB;
             if (w3 > W.back() && w3 % W.back() == 0) W.push_back(w3);
         }
+        // panel groups: a window of the first nested width (4 blocks) with at least two blocks is factorized by one
+        // STEP_PDIAG + STEP_PTRSM pair at the iteration of its first block
+        const int64_t GW = (int64_t)SOLVE_GROUP * NB;
+        const bool pg_on = tuning().panel_group > 0 && !S.cplx && !dist && !tuning().lookahead && W.size() > 1 && W[1] == GW &&
+                           nsrow < (1 << 27);       // (the kernels add 32-bit lane offsets of up to 4 * nsrow entries to uniform bases)
         for (int64_t j = 0; j < ncol_eff; j += NB, it++) {
             const int64_t nb = std::min<int64_t>(NB, ncol_eff - j);
             const int64_t e = j + nb;
             const int64_t below = nsrow - e;
             L[lev].ensure(it);
+            const int64_t w0 = (j / GW) * GW, w1 = std::min<int64_t>(w0 + GW, ncol_eff);
+            const bool grouped = pg_on && w1 - w0 > NB;
+            const size_t it0 = it - (size_t)((j - w0) / NB);
+            if (grouped) {
+                if (j == w0) {
+                    LevelSteps::Group G;
+                    G.g.a_off = psx + w0 + w0 * nsrow;
+                    for (int b = 0; b < 4; b++) { G.g.dinv_off[b] = -1; G.blk[b] = 0; }
+                    G.g.wg0 = 0; G.g.lda = (int32_t)nsrow; G.g.ncols = (int32_t)(w1 - w0); G.g.s = (int32_t)s;
+                    G.g.col0 = (int32_t)w0; G.g.below = (int32_t)(nsrow - w1); G.g.pad = 0;
+                    L[lev].pgroup[it0].push_back(G);
+                }
+                L[lev].pgroup[it0].back().blk[(size_t)((j - w0) / NB)] = L[lev].potrf[it].size();
+                grouped_blocks.insert(psx + j + j * nsrow);
+            }
             PotrfTask pt;
             pt.a_off = psx + j + j * nsrow;
-            pt.dinv_off = (below > 0) ? 0 : -1;     // slot assigned when the step is flushed
+            pt.dinv_off = (below > 0 && !grouped) ? 0 : -1;     // slot assigned when the step is flushed; >= 0: a TRSM task follows
             pt.lda = (int32_t)nsrow; pt.nb = (int32_t)nb; pt.s = (int32_t)s; pt.col0 = (int32_t)j;
             pt.ls_off = S.Lpi[s]; pt.stile0 = 0;
             pt.k1 = (int32_t)S.Super[s]; pt.nscol = (int32_t)nscol;
@@ -359,8 +385,11 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             GemmTask t = make_gemm(psx + e + j * nsrow, /*b: slot, set later*/ 0,
                                    psx + e + j * nsrow, -1, nsrow, nb, nsrow,
                                    below, nb, nb, GEMM_OVERWRITE);
-            L[lev].trsm[it].push_back(t);
+            if (!grouped) L[lev].trsm[it].push_back(t);
             if (own) out.flops_panel += (double)below * nb * nb;
+            // a grouped window's trailing updates (those of the blocks that end where it ends) run right after its
+            // STEP_PTRSM, i.e. at the iteration of its first block
+            auto &trail_here = grouped ? L[lev].trail[it0] : L[lev].trail[it];
             for (size_t lvl = 0; lvl < W.size(); lvl++) {
                 const int64_t b0 = ((e - 1) / W[lvl]) * W[lvl];                       // block of this level ending at e?
                 if (std::min<int64_t>(b0 + W[lvl], ncol_eff) != e) break;
@@ -368,6 +397,11 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     ? std::min<int64_t>((b0 / W[lvl + 1]) * W[lvl + 1] + W[lvl + 1], ncol_eff) : ncol_eff;
                 if (enc_end <= e) continue;                                           // enclosing block complete too
                 const int64_t K = e - b0, Nn = enc_end - e;
+                if (grouped && lvl == 0) {
+                    // the K = 64 update inside the window: part of the group's kernels (same flops)
+                    out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
+                    break;
+                }
                 if (dist && lvl + 1 == W.size()) {
                     // outermost update, owner-computes: one task per target outer block, kept by its owner
                     // look-ahead (Tuning::dist_lookahead): only the update of the NEXT block (c0 == e) feeds the next
@@ -401,7 +435,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
                     break;
                 }
-                L[lev].trail[it].push_back(make_gemm(
+                trail_here.push_back(make_gemm(
                     psx + e + b0 * nsrow, psx + e + b0 * nsrow,
                     psx + e + e * nsrow, -1, nsrow, nsrow, nsrow,
                     below, Nn, K, GEMM_DIRECT_SUB));
@@ -468,29 +502,34 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
     for (int lev = 0; lev < nlev; lev++) {
         LevelSteps &ls = L[lev];
         std::vector<GemmTask> deferred;             // DistTop look-ahead: far updates waiting for the next broadcast point
+        // Dinv slots of the whole level first, in iteration order (a panel group that starts at iteration it needs the
+        // slots of its later blocks).  Every block keeps its inverse for the whole life of the factor (the solves
+        // reuse it): slots are global, sum nb^2 <= 64*n entries.
+        std::vector<std::vector<uint8_t>> has_trsm(ls.potrf.size());
+        for (size_t it = 0; it < ls.potrf.size(); it++)
+            for (PotrfTask &pt : ls.potrf[it]) {
+                has_trsm[it].push_back(pt.dinv_off >= 0 ? 1 : 0);
+                pt.dinv_off = out.dinv_size;
+                out.dinv_size += (int64_t)pt.nb * pt.nb;
+            }
+        auto nolaunch = [&](const PotrfTask &pt) { return fused_by.count(pt.a_off) != 0 || grouped_blocks.count(pt.a_off) != 0; };
         for (size_t it = 0; it < ls.potrf.size(); it++) {
-            // assign Dinv slots for this step; the trsm task i pairs with the i-th potrf task
-            // that has rows below it (same push order)
-            // Every block keeps its inverse for the whole life of the factor (the solves
-            // reuse it): slots are global, sum nb^2 <= 64*n entries.
+            // the trsm task i pairs with the i-th potrf task that has one (same push order)
             size_t ti = 0;
             std::vector<PotrfTask> pts;                 // the tasks this schedule runs (all, or this rank's)
             std::vector<GemmTask> trs;
             for (size_t i = 0; i < ls.potrf[it].size(); i++) {
                 PotrfTask &pt = ls.potrf[it][i];
-                const bool has_below = (pt.dinv_off >= 0);
                 const bool own = ls.mine[it][i] != 0;
-                pt.dinv_off = out.dinv_size;
-                if (has_below) {
+                if (has_trsm[it][i]) {
                     ls.trsm[it][ti].b_off = pt.dinv_off;
                     if (own && !pt.fuse_trsm) trs.push_back(ls.trsm[it][ti]);
                     ti++;
                 }
-                out.dinv_size += (int64_t)pt.nb * pt.nb;
                 if (own) pts.push_back(pt);
             }
-            if (!fused_by.empty())
-                std::stable_partition(pts.begin(), pts.end(), [&](const PotrfTask &pt) { return fused_by.count(pt.a_off) == 0; });
+            if (!fused_by.empty() || !grouped_blocks.empty())
+                std::stable_partition(pts.begin(), pts.end(), [&](const PotrfTask &pt) { return !nolaunch(pt); });
             int64_t stiles = 0;
             const int64_t tmap_off = (int64_t)out.solve_tile_task.size();
             int32_t ti32 = 0;
@@ -508,20 +547,20 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             st.count = (int64_t)pts.size();
             // blocks that the previous iteration's trailing update completes inside k_gemm128 (the workgroup of tile
             // (0, 0) factorizes the block right after its stores): they come last in the step and have no launch here
-            for (size_t i = 0; i < pts.size(); i++)
+            for (size_t i = 0; i < pts.size(); i++) {
                 if (fused_by.count(pts[i].a_off)) {
                     out.gemm[(size_t)fused_by[pts[i].a_off]].fuse_potrf = (int32_t)(st.first + (int64_t)i);
                     st.nfused++;
-                }
+                } else if (grouped_blocks.count(pts[i].a_off)) { st.nfused++; st.ngrouped++; }
+            }
             if (tuning().tiny_max > 0 && !S.cplx) {
                 out.potrf_order.resize(out.potrf.size());           // steps of other schedules' making: none
                 for (int pass = 0; pass < 3; pass++)
                     for (size_t i = 0; i < pts.size(); i++) {
-                        const bool fz = fused_by.count(pts[i].a_off) != 0;
-                        const int cls = fz ? 2 : (pts[i].nb <= 16 ? 0 : 1);
+                        const int cls = nolaunch(pts[i]) ? 2 : (pts[i].nb <= 16 ? 0 : 1);
                         if (cls == pass) out.potrf_order.push_back((int32_t)i);
                     }
-                for (auto &pt : pts) st.nsmall += (pt.nb <= 16 && !fused_by.count(pt.a_off)) ? 1 : 0;
+                for (auto &pt : pts) st.nsmall += (pt.nb <= 16 && !nolaunch(pt)) ? 1 : 0;
             }
             st.ntiles = st.count;
             st.stiles = stiles;
@@ -529,6 +568,32 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             out.potrf.insert(out.potrf.end(), pts.begin(), pts.end());
             if (st.count > 0) out.steps.push_back(st);
             flush_gemm(out, trs, lev, S, 1);
+            if (!ls.pgroup[it].empty()) {
+                // the panel groups that start here: their diagonal windows, then the rows below them
+                Step sd;
+                sd.kind = STEP_PDIAG; sd.level = lev; sd.big = 0; sd.trsm = 0; sd.flags = 0; sd.nsmall = 0;
+                sd.first = (int64_t)out.pgroups.size(); sd.count = (int64_t)ls.pgroup[it].size();
+                sd.ntiles = sd.count; sd.stiles = 0; sd.tmap_off = 0;
+                Step sr = sd;
+                sr.kind = STEP_PTRSM; sr.tmap_off = (int64_t)out.pg_wg_task.size();
+                // rows of a panel per workgroup: 128 or 64 (k_panel_trsm_reg: the rows in registers), 32 or 16 (k_panel_trsm: in LDS)
+                const int pgv = tuning().panel_group;
+                const int64_t rows = pgv >= 128 || pgv < 16 ? 128 : (pgv >= 64 ? 64 : (pgv >= 32 ? 32 : 16));
+                sr.ngrouped = (int32_t)rows;
+                int64_t wgs = 0;
+                int32_t gi = 0;
+                for (LevelSteps::Group &G : ls.pgroup[it]) {
+                    for (int b = 0; b * NB < G.g.ncols; b++) G.g.dinv_off[b] = ls.potrf[it + (size_t)b][G.blk[b]].dinv_off;
+                    G.g.wg0 = wgs;
+                    const int64_t nw = ((int64_t)G.g.below + rows - 1) / rows;
+                    out.pg_wg_task.insert(out.pg_wg_task.end(), (size_t)nw, gi++);
+                    wgs += nw;
+                    out.pgroups.push_back(G.g);
+                }
+                sr.ntiles = wgs;
+                out.steps.push_back(sd);
+                if (wgs > 0) out.steps.push_back(sr);
+            }
             bool block_end = false;
             for (BcastPoint bp : ls.bcast[it]) {        // finished blocks (or pieces), before anybody's update reads them
                 bp.step = bp.wait_step = (int64_t)out.steps.size();
@@ -556,7 +621,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             const size_t g0 = out.gemm.size();
             flush_gemm(out, ls.trail[it], lev, S, 0, ls.rest[it].empty() ? 0 : STEP_JOIN);
             fused_by.clear();
-            if (tuning().fuse_potrf && !S.cplx && !tuning().lookahead && !truncated_any) {
+            if (tuning().fuse_potrf && !S.cplx && !tuning().lookahead && !truncated_any && tuning().panel_group <= 0) {
                 // The one trailing task of a supernode at this iteration is the last writer of its next diagonal block
                 // (target origin c_off = that block): routed to the big-tile kernel, its tile (0, 0) holds the block
                 for (size_t g = g0; g < out.gemm.size(); g++) {
@@ -826,6 +891,9 @@ std::string check_host_copy_plan(const Symbolic &S, const Schedule &sc, const st
             if (st.kind == STEP_POTRF) {
                 const PotrfTask &t = sc.potrf[(size_t)ti];
                 mark(S.Lpx[t.s], S.Lpx[t.s + 1] - 1, (int64_t)si);         // the block (and, fused, the rows below it)
+            } else if (st.kind == STEP_PDIAG || st.kind == STEP_PTRSM) {
+                const PanelGroup &g = sc.pgroups[(size_t)ti];
+                mark(S.Lpx[g.s], S.Lpx[g.s + 1] - 1, (int64_t)si);         // the window, the rows below it
             } else {
                 const GemmTask &t = sc.gemm[(size_t)ti];
                 if (t.mode == GEMM_SCATTER_SUB) {
@@ -903,9 +971,48 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
             if (last(t.a_off, t.lda, t.nb, t.lda) >= xs) return bad("fused potrf task panel", (int64_t)i);
         }
     }
+    int64_t ngrouped_blocks = 0, ngrouped_steps = 0;
+    for (size_t i = 0; i < sc.pgroups.size(); i++) {
+        // a panel group is a window of one supernode: everything its kernels index follows from (s, col0, ncols)
+        const PanelGroup &g = sc.pgroups[i];
+        if (S.cplx || g.s < 0 || g.s >= S.nsuper) return bad("panel group supernode", (int64_t)i);
+        const int64_t nscol = S.Super[g.s + 1] - S.Super[g.s], nsrow = S.Lpi[g.s + 1] - S.Lpi[g.s];
+        if (g.ncols <= NB || g.ncols > SOLVE_GROUP * NB || g.col0 < 0 || g.col0 % (SOLVE_GROUP * NB) != 0 || (int64_t)g.col0 + g.ncols > nscol)
+            return bad("panel group columns", (int64_t)i);
+        if (nsrow >= (1 << 27)) return bad("panel group leading dimension", (int64_t)i);
+        if (g.lda != nsrow || g.below != nsrow - g.col0 - g.ncols || g.a_off != S.Lpx[g.s] + g.col0 + (int64_t)g.col0 * nsrow)
+            return bad("panel group panel", (int64_t)i);
+        if (last(g.a_off, (int64_t)g.ncols + g.below, g.ncols, g.lda) >= xs) return bad("panel group extent", (int64_t)i);
+        for (int b = 0; b * NB < g.ncols; b++) {
+            const int64_t nb = std::min<int64_t>(NB, g.ncols - b * NB);
+            if (g.dinv_off[b] < 0 || g.dinv_off[b] + nb * nb > ds) return bad("panel group Dinv", (int64_t)i);
+            ngrouped_blocks++;
+        }
+    }
     for (size_t i = 0; i < sc.steps.size(); i++) {
         const Step &st = sc.steps[i];
         if (st.first < 0 || st.count < 0) return bad("step range", (int64_t)i);
+        if (st.kind == STEP_PDIAG || st.kind == STEP_PTRSM) {
+            if (st.first + st.count > (int64_t)sc.pgroups.size()) return bad("panel group step range", (int64_t)i);
+            if (st.kind == STEP_PDIAG) continue;
+            // the rows below the windows, `rows` per workgroup: the table lists every workgroup of every task, in order
+            const int64_t rows = st.ngrouped;
+            if (rows != 16 && rows != 32 && rows != 64 && rows != 128) return bad("panel group rows per workgroup of step", (int64_t)i);
+            if (i == 0 || sc.steps[i - 1].kind != STEP_PDIAG || sc.steps[i - 1].first != st.first || sc.steps[i - 1].count != st.count)
+                return bad("panel group solve without its diagonal step", (int64_t)i);
+            if (st.tmap_off < 0 || st.tmap_off + st.ntiles > (int64_t)sc.pg_wg_task.size()) return bad("panel group step workgroups", (int64_t)i);
+            int64_t at = 0;
+            for (int64_t k = 0; k < st.count; k++) {
+                const PanelGroup &g = sc.pgroups[(size_t)(st.first + k)];
+                if (g.wg0 != at) return bad("panel group workgroup prefix of step", (int64_t)i);
+                const int64_t nw = ((int64_t)g.below + rows - 1) / rows;
+                for (int64_t b = 0; b < nw; b++)
+                    if (at + b >= st.ntiles || sc.pg_wg_task[(size_t)(st.tmap_off + at + b)] != (int32_t)k) return bad("panel group workgroup table of step", (int64_t)i);
+                at += nw;
+            }
+            if (at != st.ntiles) return bad("panel group workgroup count of step", (int64_t)i);
+            continue;
+        }
         if (st.kind == STEP_POTRF) {
             if (st.first + st.count > (int64_t)sc.potrf.size()) return bad("potrf step range", (int64_t)i);
             if (!sc.potrf_order.empty()) {
@@ -923,8 +1030,9 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
                     } else if (o < st.count - st.nfused) return bad("potrf order: launched task among the fused", (int64_t)i);
                 }
             } else if (st.nsmall != 0) return bad("potrf step without order list", (int64_t)i);
-            if (st.nfused < 0 || st.nfused > st.count) return bad("potrf step fused count", (int64_t)i);
-            nfused_steps += st.nfused;
+            if (st.nfused < 0 || st.nfused > st.count || st.ngrouped < 0 || st.ngrouped > st.nfused) return bad("potrf step fused count", (int64_t)i);
+            nfused_steps += st.nfused - st.ngrouped;
+            ngrouped_steps += st.ngrouped;
             if (st.tmap_off < 0 || st.tmap_off + st.stiles > (int64_t)sc.solve_tile_task.size()) return bad("potrf step solve tiles", (int64_t)i);
             for (int64_t b = 0; b < st.stiles; b++) {
                 const int32_t ti = sc.solve_tile_task[(size_t)(st.tmap_off + b)];
@@ -952,6 +1060,7 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         }
     }
     if (nfused_refs != nfused_steps) return bad("fused potrf tasks without an update that runs them", nfused_steps - nfused_refs);
+    if (ngrouped_blocks != ngrouped_steps) return bad("diagonal blocks without a launch and without a panel group", ngrouped_steps - ngrouped_blocks);
     for (size_t i = 0; i < sc.bcasts.size(); i++) {
         const BcastPoint &b = sc.bcasts[i];
         if (b.lo < 0 || b.count <= 0 || b.lo + b.count > xs || b.step < 0 || b.step > (int64_t)sc.steps.size() || b.root < 0)
@@ -973,6 +1082,7 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
                 }
                 continue;
             }
+            if (st.kind != STEP_GEMM) return bad("broadcast in flight over a panel group", (int64_t)i);   // (never built together)
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const GemmTask &t = sc.gemm[(size_t)ti];
                 if (!b.mine && hits(t.a_off, t.M, t.K, t.lda)) return bad("broadcast in flight: A operand of a task", (int64_t)i);

@@ -136,7 +136,28 @@ struct UpdatePair {
     int64_t rm_off;     // offset of its relative map (ndrow2 entries)
 };
 
-enum StepKind : int32_t { STEP_POTRF = 0, STEP_GEMM = 1 };
+// Panel groups (round 3, Tuning::panel_group): the panel chain of a supernode -- POTRF of a 64-column diagonal block, TRSM
+// of the rows below it, K = 64 update of the rest of the 256-column window, three dependent launches per 64 columns and
+// the part of a factorization that runs far below the rate of the big updates -- is taken 256 columns at a time:
+//   STEP_PDIAG  one workgroup factorizes the whole diagonal window (<= 256 x 256: its up to four diagonal blocks, their
+//               inverses and the blocks between them; k_panel_diag), then
+//   STEP_PTRSM  the rows below the window are solved against it in ONE pass (k_panel_trsm: the forward chain of the
+//               solve groups with the panel's rows as right-hand sides -- column-major L IS the row-major image of them),
+// and the window's K = 256 (and, where a 1024-column block ends, K = 1024) trailing updates follow as before: three
+// launches per 256 columns instead of thirteen.  The 64-column PotrfTasks stay in the schedule (the solve work lists are
+// built over them) as tasks without a launch (Step::nfused counts them at the end of their steps).
+struct PanelGroup {
+    int64_t a_off;                      // L[col0][col0]: origin of the diagonal window in Lx
+    int64_t dinv_off[4];                // inverses of the window's diagonal blocks (ld = block width)
+    int64_t wg0;                        // first workgroup of this task in its STEP_PTRSM launch
+    int32_t lda;                        // = nsrow
+    int32_t ncols;                      // columns of the window (<= 256; blocks of NB, the last may be narrower)
+    int32_t s;                          // supernode (info)
+    int32_t col0;                       // first column of the window inside s (info = col0 + j + 1)
+    int32_t below;                      // rows below the window: lda - col0 - ncols
+    int32_t pad;
+};
+enum StepKind : int32_t { STEP_POTRF = 0, STEP_GEMM = 1, STEP_PDIAG = 2, STEP_PTRSM = 3 };
 struct Step {
     int32_t kind;
     int32_t level;
@@ -152,7 +173,7 @@ struct Step {
                         // blocks of at most 16 columns (k_potrf16: one wave per block), the rest go to k_potrf64
     int32_t nfused = 0; // STEP_POTRF: the LAST nfused tasks of the step are factorized by the trailing update that completes
                         // them (GemmTask::fuse_potrf) and have no launch here; the solves still see them as tasks of the step
-    int32_t pad = 0;
+    int32_t ngrouped = 0; // STEP_POTRF: of those, the blocks that a panel group factorizes (STEP_PDIAG); STEP_PTRSM: rows per workgroup
 };
 // Look-ahead: the part of an outermost trailing update that lies beyond the NEXT outer block does not feed the
 // next block's panel chain, so it runs on a second stream (STEP_SIDE) next to that chain; whatever touches its
@@ -209,6 +230,8 @@ struct Schedule {
     // solve work lists are built over it).  Empty otherwise.
     std::vector<int32_t> potrf_order;
     std::vector<GemmTask> gemm;
+    std::vector<PanelGroup> pgroups;    // STEP_PDIAG / STEP_PTRSM tasks (a PTRSM step runs the groups of the PDIAG step before it)
+    std::vector<int32_t> pg_wg_task;    // STEP_PTRSM: workgroup -> task (relative to the step's first), Step::tmap_off / ntiles
     std::vector<UpdatePair> pairs;
     std::vector<Step> steps;
     // One entry per GEMM workgroup, indexed by blockIdx.x inside its launch: the task (index relative
@@ -255,7 +278,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax = 0 /* 256 real, 128 complex; 0: no wide lists */);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; int panel_group = 64; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -861,18 +861,18 @@ __global__ __launch_bounds__(256) void k_solve_diag_mma(
 // Im(block) against the pair-swapped image of Y, as in k_solve_fwd_mma / k_solve_bwd_mma.
 //------------------------------------------------------------------------------
 constexpr int SG_CW = 16;      // real columns of Y per workgroup of k_solve_group_mma
-template <bool TRANS, int E, int MAXBLK, int CW = SG_CW>
-__global__ __launch_bounds__(256) void k_solve_group_mma(
-    const SolveGroupTask *__restrict__ groups, const double *__restrict__ Dinv, const double *__restrict__ Lx,
-    double *__restrict__ Y, int64_t ldr, int nrhs)
+// The chain of one group on the CW columns [j0, j0 + nj) of the image y0 (row r of the group at y0 + r * ldr), Yg: the
+// workgroup's LDS image of those rows.  Shared by the solves (k_solve_group_mma: y0 = the group's rows of Y) and the
+// factorization (k_panel_trsm: y0 = the group's columns of the PANEL, whose rows are the right-hand sides).
+template <bool TRANS, int E, int MAXBLK, int CW, int RING = 0 /* register sets of L's blocks in flight; 0: as many as there are steps, up to 8 (4 complex) */>
+__device__ __forceinline__ void solve_group_mma_body(
+    const SolveGroupTask &t, const double *__restrict__ Dinv, const double *__restrict__ Lx,
+    double *__restrict__ y0, int64_t ldr, int j0, int nj, double (*Yg)[CW + 2])
 {
     constexpr int NS = MAXBLK * (MAXBLK + 1) / 2;
-    constexpr int NSETS = (E == 1) ? (NS < 8 ? NS : 8) : (NS < 4 ? NS : 4);
-    __shared__ double Yg[MAXBLK * NB][CW + 2];
-    const SolveGroupTask t = groups[blockIdx.x];
+    constexpr int NSETS = RING > 0 ? (RING < NS ? RING : NS) : (E == 1) ? (NS < 8 ? NS : 8) : (NS < 4 ? NS : 4);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int ncols = t.ncols, nblk = (ncols + NB - 1) / NB;
-    double *__restrict__ y0 = Y + (int64_t)t.x0 * ldr;
     // A operand of step (c, b): A[i][k], i = 16w + lane%16, k = 4q + lane/16 -- entry (i, k) of the block, or
     // the conjugate of entry (k, i) when TRANS; [q] real parts, [16 + q] imaginary parts
     auto load = [&](int b, int c, double (&m)[16 * E]) {
@@ -896,10 +896,6 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
         }
     };
     {
-        // blockIdx.y: which CW real columns of Y this workgroup sweeps (a group's chain is MFMA-bound on one
-        // CU -- 10 steps x 64 x 64 x nrhs -- so the right-hand sides are spread over workgroups)
-        const int j0 = blockIdx.y * CW;
-        const int nj = min(CW, nrhs - j0);
         double m[NSETS][16 * E];
 #pragma unroll
         for (int u = 0; u < NSETS; u++) {
@@ -971,6 +967,47 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
             }
         }
     }
+}
+
+template <bool TRANS, int E, int MAXBLK, int CW = SG_CW>
+__global__ __launch_bounds__(256) void k_solve_group_mma(
+    const SolveGroupTask *__restrict__ groups, const double *__restrict__ Dinv, const double *__restrict__ Lx,
+    double *__restrict__ Y, int64_t ldr, int nrhs)
+{
+    __shared__ double Yg[MAXBLK * NB][CW + 2];
+    const SolveGroupTask t = groups[blockIdx.x];
+    // blockIdx.y: which CW real columns of Y this workgroup sweeps (a group's chain is MFMA-bound on one
+    // CU -- 10 steps x 64 x 64 x nrhs -- so the right-hand sides are spread over workgroups)
+    const int j0 = blockIdx.y * CW;
+    solve_group_mma_body<TRANS, E, MAXBLK, CW>(t, Dinv, Lx, Y + (int64_t)t.x0 * ldr, ldr, j0, min(CW, nrhs - j0), Yg);
+}
+
+//------------------------------------------------------------------------------
+// k_panel_trsm (factorization, STEP_PTRSM): the rows below a panel group's diagonal window, X * L_w^T = A for the window's
+// <= 256 columns, in place.  Transposed, that is L_w * X^T = A^T: a forward solve with the window as the group and the
+// ROWS of the panel as right-hand sides -- and the column-major panel (column c of the window at c * nsrow, row r at + r)
+// is exactly the row-major image the group chain works on (row c of the image at c * ldr, right-hand side r at + r, ldr =
+// nsrow).  So one workgroup takes ROWS rows of the panel through the whole window: the four products with the block
+// inverses and the six updates between the blocks, ten 64 x 64 x ROWS MFMA steps on an LDS image of its rows, L's blocks
+// in a ring of register sets -- where the per-block schedule needed four TRSM and three trailing launches, each reading
+// and writing the window's columns again.
+//------------------------------------------------------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(256, ROWS <= 32 ? 2 : 1) void k_panel_trsm(
+    const PanelGroup *__restrict__ groups, const int32_t *__restrict__ wg_task, const double *__restrict__ Dinv, double *Lx)
+{
+    __shared__ double Yg[SOLVE_GROUP * NB][ROWS + 2];
+    const PanelGroup g = groups[wg_task[blockIdx.x]];
+    SolveGroupTask t;
+    t.a_off = g.a_off;
+#pragma unroll
+    for (int b = 0; b < SOLVE_GROUP; b++) t.dinv_off[b] = g.dinv_off[b];
+    t.lda = g.lda; t.ncols = g.ncols; t.x0 = 0; t.pad = 0;
+    const int r0 = g.ncols + (int)((int64_t)blockIdx.x - g.wg0) * ROWS;      // first row of this workgroup below the window's origin
+    // image origin: the window's first column, at the row of the window's first row (so that "right-hand side" r0 + j
+    // is the row r0 + j below the diagonal block's origin)
+    // (three register sets of L's blocks in flight: the chain of a workgroup is short, what counts is how many workgroups a CU holds)
+    solve_group_mma_body<false, 1, SOLVE_GROUP, ROWS, 3>(t, Dinv, Lx, Lx + g.a_off, (int64_t)g.lda, r0, min(ROWS, g.ncols + g.below - r0), Yg);
 }
 
 //------------------------------------------------------------------------------
@@ -1305,6 +1342,148 @@ __global__ __launch_bounds__(WIDE_THREADS) void k_solve_bwd_wide(
                 if (c < ncols && jo + l15 < nj) atomic_add_f64(x1 + (int64_t)c * ldr + jo, -v);
             }
     __syncthreads();                                              // the next segment overwrites the LDS images
+    }
+}
+
+//------------------------------------------------------------------------------
+// k_panel_trsm_reg (STEP_PTRSM, 64 rows per workgroup): the same solve with the roles turned round.  k_panel_trsm above
+// keeps the panel's rows in LDS and L's blocks in registers, so every workgroup fetches the window's ten blocks (320 KB)
+// for ROWS rows of the panel: ten times the panel's own bytes out of L2 at 16 rows per workgroup, which is what bounds
+// it.  Here every wave keeps ITS 16 rows of the panel -- all 256 columns, 64 doubles per lane -- in registers from the
+// first load to the last store, and the blocks of the window go through LDS once per workgroup, double-buffered, one
+// barrier per block.  The result registers of one product (16 x 64, rows along lane % 16) ARE the operand registers of
+// the next (k_trsm64's layout), so X_b never leaves the register file between the product with the inverse that makes
+// it and the updates that use it: T_c -= X_b L(c,b)^T for b < c, then X_c = T_c W_c^T, block after block.
+//------------------------------------------------------------------------------
+template <int WAVES>      // 4: 64 rows per workgroup, two workgroups per CU; 8: 128 rows, one workgroup (the blocks of the window are fetched half as often)
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_panel_trsm_reg(
+    const PanelGroup *__restrict__ groups, const int32_t *__restrict__ wg_task, const double *__restrict__ Dinv, double *Lx)
+{
+    __shared__ double Bs[2][NB][NB + 2];                 // Bs[.][n][k]: block (c, b) of the window as L(64c + n, 64b + k), or W_c(n, k)
+    const int gi = wg_task[blockIdx.x];
+    const PanelGroup g = groups[gi];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ncols = g.ncols, nblk = (ncols + NB - 1) / NB;
+    const int64_t lda = g.lda;
+    const int nrows = ncols + g.below;                   // rows of the panel from the window's first row down
+    const int r = ncols + (int)((int64_t)blockIdx.x - g.wg0) * (16 * WAVES) + 16 * w + l15;
+    const bool ok = r < nrows;
+    double *Ar = Lx + g.a_off + (ok ? r : nrows - 1);    // this lane's row (clamped: loaded, never stored)
+    const uint32_t roff = (uint32_t)(ok ? r : nrows - 1) + (uint32_t)l4 * (uint32_t)lda;   // ... and its lane offset from a column's top
+    // the stages: for c = 0 .. nblk - 1: blocks (c, 0) .. (c, c - 1), then the inverse of block c
+    auto stage_bc = [](int s, int &b, int &c) { c = 0; while (s > c) { s -= c + 1; c++; } b = s; };   // s -> (b <= c)
+    const int nstages = nblk * (nblk + 1) / 2;
+    constexpr int NS = 16 * 4 / WAVES;                   // entries of a 64 x 64 block per thread
+    constexpr int KS = WAVES;                            // columns of a block between two entries of a thread
+    double sreg[NS];
+    // (addresses are kept affine -- one pointer and a uniform stride per batch of loads -- wherever the block is known to
+    // be full: with a clamp or a select per load the compiler computes every address of a batch up front, 64-bit each)
+    auto fetch = [&](int s) {                            // the block of stage s -> sreg (thread: n = idx % 64, k = idx / 64)
+        int b, c;
+        stage_bc(s, b, c);
+        const int nbc = min(NB, ncols - NB * c);
+        const int n = tid & 63, k0 = tid >> 6;
+        if (b == c) {
+            // the inverse of block c: nbc x nbc, ld = nbc (the last block of a window may be narrower than 64)
+            const double *p = Dinv + groups[gi].dinv_off[c] + min(n, nbc - 1);   // (read in place: indexing a private copy of g by c would put it in scratch)
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int k = k0 + KS * i;
+                sreg[i] = keep_if(p[min(k, nbc - 1) * nbc], n < nbc && k < nbc);
+            }
+        } else {
+            // block (c, b), b < c: all 64 columns of block b exist
+            // (uniform base + 32-bit lane offset: the saddr form of global_load, no 64-bit address per load in VGPRs;
+            // lda < 2^27 for a panel group, schedule.cpp)
+            const uint32_t voff = (uint32_t)min(n, nbc - 1) + (uint32_t)k0 * (uint32_t)lda;
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const double *pu = Lx + g.a_off + NB * c + (int64_t)(NB * b + KS * i) * lda;
+                sreg[i] = keep_if(pu[voff], n < nbc);
+            }
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const int idx = tid + 64 * WAVES * i;
+            Bs[buf][idx & 63][idx >> 6] = sreg[i];
+        }
+    };
+    fetch(0);
+    // this wave's rows: t[c][q] = entry (r, 64 c + 4 q + lane / 16), the operand layout of the products
+    double t[SOLVE_GROUP][16];
+#pragma unroll
+    for (int c = 0; c < SOLVE_GROUP; c++) {
+        if (NB * (c + 1) <= ncols) {                     // a full block (uniform)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double *pu = Lx + g.a_off + (int64_t)(NB * c + 4 * q) * lda;     // uniform
+                t[c][q] = pu[roff];
+            }
+        } else if (NB * c < ncols) {                     // the last, narrower block of a window
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int col = NB * c + 4 * q + l4;
+                t[c][q] = keep_if(Ar[(int64_t)min(col, ncols - 1) * lda], col < ncols);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) t[c][q] = 0.0;
+        }
+    }
+    put(0);
+    __syncthreads();
+    if (nstages > 1) fetch(1);
+#pragma unroll
+    for (int c = 0; c < SOLVE_GROUP; c++) {
+        if (c >= nblk) break;                            // uniform
+#pragma unroll
+        for (int b = 0; b <= c; b++) {
+            const int s = c * (c + 1) / 2 + b;           // (a constant after unrolling)
+            const double (*B)[NB + 2] = Bs[s & 1];
+            // two of the four 16-column tiles of the result at a time (16 accumulator registers instead of 32: the rows
+            // of the panel take 128 of the 256 a lane may have at two waves per SIMD).  The product with the inverse goes
+            // from the last tile pair to the first and skips what lies above W's diagonal: tile cb needs the operand
+            // registers q <= 4 cb + 3 only, so X_c can replace T_c in place, pair after pair.
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int cb0 = (b == c) ? 2 - 2 * h : 2 * h;
+                v4d acc[2];
+                acc[0] = (v4d){0.0, 0.0, 0.0, 0.0};
+                acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int cb = cb0 + u;
+                        if (b == c && q > 4 * cb + 3) continue;          // above the diagonal of W: zeros
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(B[16 * cb + l15][4 * q + l4], t[b][q], acc[u], 0, 0, 0);
+                    }
+                // result (r, 16 cb + lane / 16 + 4 gq) = operand register 4 cb + gq
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int cb = cb0 + u;
+                        if (b == c) t[c][4 * cb + gq] = acc[u][gq]; else t[c][4 * cb + gq] -= acc[u][gq];
+                    }
+            }
+            if (b == c && ok) {
+                // X_c is final
+                const int nbc = min(NB, ncols - NB * c);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    double *pu = Lx + g.a_off + (int64_t)(NB * c + 4 * q) * lda;          // uniform
+                    if (4 * q + l4 < nbc) pu[roff] = t[c][q];
+                }
+            }
+            if (s + 1 < nstages) {
+                put((s + 1) & 1);                        // (fetched while this stage was multiplied)
+                __syncthreads();
+                if (s + 2 < nstages) fetch(s + 2);
+            }
+        }
     }
 }
 

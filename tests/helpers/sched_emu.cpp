@@ -164,6 +164,73 @@ void run(const Symbolic &S, const Schedule &sc, int64_t ncols_asm, const int64_t
             } else
                 for (int64_t ti = st.first; ti < st.first + st.count - st.nfused; ti++) todo.push_back(ti);   // (the fused ones are last)
             for (int64_t ti : todo) host_potrf(ti);
+        } else if (st.kind == STEP_PDIAG) {
+            if (hostrun::use_device_source >= 3) {
+                hipcpu::launch(st.count, 256, [&] { k_panel_diag(sc.pgroups.data() + st.first, Lx, Dinv.data(), info.data()); });
+            } else
+            for (int64_t gi = st.first; gi < st.first + st.count; gi++) {
+                // plain loops: Cholesky of the ncols x ncols window, then the inverse of each 64-column diagonal block
+                const PanelGroup &g = sc.pgroups[(size_t)gi];
+                double *A = Lx + g.a_off; const int nc = g.ncols; const int64_t lda = g.lda;
+                bool failed = false;
+                for (int j = 0; j < nc; j++) {
+                    double d = A[j + j * lda];
+                    if (!(d > 0.0) && !failed) { failed = true; if (info[g.s] == 0) info[g.s] = g.col0 + j + 1; }
+                    double ljj = std::sqrt(d);
+                    A[j + j * lda] = ljj;
+                    for (int i = j + 1; i < nc; i++) A[i + j * lda] /= ljj;
+                    for (int k = j + 1; k < nc; k++)
+                        for (int i = k; i < nc; i++) A[i + k * lda] -= A[i + j * lda] * A[k + j * lda];
+                }
+                for (int b = 0; b * NB < nc; b++) {
+                    const int nb = std::min(NB, nc - b * NB);
+                    const double *Ab = A + b * NB + (int64_t)b * NB * lda;
+                    double *D = Dinv.data() + g.dinv_off[b];
+                    for (int c = 0; c < nb; c++) {
+                        std::vector<double> x(nb, 0.0); x[c] = 1.0;
+                        for (int k = 0; k < nb; k++) {
+                            x[k] /= Ab[k + k * lda];
+                            for (int i = k + 1; i < nb; i++) x[i] -= Ab[i + k * lda] * x[k];
+                        }
+                        for (int i = 0; i < nb; i++) D[i + c * nb] = (i >= c) ? x[i] : 0.0;
+                    }
+                }
+            }
+        } else if (st.kind == STEP_PTRSM) {
+            // the workgroup table: every workgroup of every task, in order
+            {
+                int64_t at = 0;
+                for (int64_t k = 0; k < st.count; k++) {
+                    const PanelGroup &g = sc.pgroups[(size_t)(st.first + k)];
+                    if (g.wg0 != at) info[S.nsuper + 1] = -1;
+                    const int64_t nw = ((int64_t)g.below + st.ngrouped - 1) / st.ngrouped;
+                    for (int64_t b = 0; b < nw; b++)
+                        if (at + b >= st.ntiles || sc.pg_wg_task[(size_t)(st.tmap_off + at + b)] != (int32_t)k) info[S.nsuper + 1] = -1;
+                    at += nw;
+                }
+                if (at != st.ntiles) info[S.nsuper + 1] = -1;
+            }
+            if (hostrun::use_device_source >= 3) {
+                const PanelGroup *pg = sc.pgroups.data() + st.first;
+                const int32_t *wt = sc.pg_wg_task.data() + st.tmap_off;
+                if (st.ngrouped == 128) hipcpu::launch(st.ntiles, 512, [&] { k_panel_trsm_reg<8>(pg, wt, Dinv.data(), Lx); });
+                else if (st.ngrouped == 64) hipcpu::launch(st.ntiles, 256, [&] { k_panel_trsm_reg<4>(pg, wt, Dinv.data(), Lx); });
+                else if (st.ngrouped == 32) hipcpu::launch(st.ntiles, 256, [&] { k_panel_trsm<32>(pg, wt, Dinv.data(), Lx); });
+                else hipcpu::launch(st.ntiles, 256, [&] { k_panel_trsm<16>(pg, wt, Dinv.data(), Lx); });
+            } else
+            for (int64_t gi = st.first; gi < st.first + st.count; gi++) {
+                // plain loops: X * L_w^T = A for the rows below the window, column by column
+                const PanelGroup &g = sc.pgroups[(size_t)gi];
+                double *A = Lx + g.a_off; const int nc = g.ncols; const int64_t lda = g.lda;
+                for (int j = 0; j < nc; j++) {
+                    const double ljj = A[j + j * lda];
+                    for (int64_t r = nc; r < nc + g.below; r++) {
+                        double v = A[r + j * lda];
+                        for (int k = 0; k < j; k++) v -= A[r + k * lda] * A[j + k * lda];
+                        A[r + j * lda] = v / ljj;
+                    }
+                }
+            }
         } else if (hostrun::use_device_source >= 3 && !(st.flags & STEP_TINY)) {
             // exactly the engine's GEMM launches of a real factor
             const GemmTask *tk = sc.gemm.data() + st.first;
@@ -234,6 +301,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 14) tuning().tiny_max = value;
     else if (key == 26) tuning().fuse_potrf = value;
     else if (key == 27) tuning().deterministic = value;
+    else if (key == 28) tuning().panel_group = value;
     else if (key == 100) hostrun::use_device_source = value;    // run the product's host-runnable kernels
 }
 
@@ -309,6 +377,26 @@ int emu_schedule_classes(int64_t n, int64_t nsuper, const int64_t *Super, const 
     for (const Step &st : sc.steps) {
         if (st.kind == STEP_GEMM && (st.flags & STEP_TINY)) { out[0] += st.count; out[1]++; }
         if (st.kind == STEP_POTRF) out[2] += st.nsmall;
+    }
+    out[4] = check_schedule_bounds(S, sc).empty() ? 1 : 0;
+    return 0;
+}
+
+// launches of the full schedule under the current tuning, by kind: out[0] POTRF steps that launch anything, out[1] GEMM
+// steps, out[2] STEP_PDIAG, out[3] STEP_PTRSM, out[4] 1 if check_schedule_bounds accepts the schedule
+int emu_schedule_counts(int64_t n, int64_t nsuper, const int64_t *Super, const int64_t *Lpi, const int64_t *Lpx,
+                        const int64_t *Ls, int64_t ssize, int64_t xsize, int64_t *out)
+{
+    Symbolic S; S.n = n; S.nsuper = nsuper; S.ssize = ssize; S.xsize = xsize;
+    S.Super = Super; S.Lpi = Lpi; S.Lpx = Lpx; S.Ls = Ls;
+    if (!validate_symbolic(S).empty()) return -4;
+    Schedule sc; build_schedule(S, nsuper, 0, sc);
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (const Step &st : sc.steps) {
+        if (st.kind == STEP_POTRF) out[0] += st.count > st.nfused ? 1 : 0;
+        else if (st.kind == STEP_GEMM) out[1]++;
+        else if (st.kind == STEP_PDIAG) out[2]++;
+        else if (st.kind == STEP_PTRSM) out[3]++;
     }
     out[4] = check_schedule_bounds(S, sc).empty() ? 1 : 0;
     return 0;

@@ -539,3 +539,11 @@ def test_deterministic_mode_through_the_abi(engine, name):
     workgroups one after the other, so identical bits are no news here; the GPU test of the same name is the real one)"""
     import test_gpu_parity as tp
     tp.test_deterministic_mode_gives_identical_bits(engine, name)
+
+
+@pytest.mark.parametrize("case,rows", [("dense130", 64), ("dense300", 32), ("dense700", 128), ("lap3d_8_metis", 128), ("lap3d_8_npd200", 16), ("arrow800", 64)])
+def test_panel_groups_through_the_abi(engine, case, rows):
+    """tuning key 28: the engine's own launch code for STEP_PDIAG / STEP_PTRSM (k_panel_diag, k_panel_trsm from their
+    source) on small cases -- the body of the GPU test of the same name"""
+    import test_gpu_parity as tp
+    tp.test_panel_groups(engine, case, rows)

@@ -368,7 +368,7 @@ def test_blas_statistics_are_filled(which):
     """Common->cholmod_gpu_*_calls/_time (cholmod.h:966-986; cholmod_l_gpu_stats prints them,
     CHOLMOD/Check/cholmod_check.c:608-672): the patched build is compiled with BLAS_TIMER as the reference's GPU
     build is, so both calls and times must move with every factorization"""
-    g = load_golden("demo_bcsstk02")
+    g = load_golden("lap3d_8_metis")      # (several supernodes: update launches as well as panel launches)
     r = _cholmod(which)
     r.load(g["n"], g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
     r.analyze(perm=g["Perm"], supernodal=2)

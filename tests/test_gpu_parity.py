@@ -943,3 +943,71 @@ def test_deterministic_mode_gives_identical_bits(engine, name):
         L.close()
     finally:
         engine.set_tuning(27, 0)
+
+
+@pytest.mark.parametrize("rows", [128, 64, 32, 16])
+@pytest.mark.parametrize("case", ["dense130", "dense300", "dense700", "dense1100", "dense1733", "lap3d_8_metis", "elast27_4_metis",
+                                  "demo_bcsstk02", "lap3d_8_npd200", "tcov_r5lo", "arrow800", "blocks1100"])
+def test_panel_groups(engine, case, rows):
+    """tuning key 28 (schedule.hpp, STEP_PDIAG / STEP_PTRSM): the panel chain 256 columns at a time -- k_panel_diag on the
+    diagonal window, k_panel_trsm<rows> on the rows below it -- gives the factor of the per-block chain: dense supernodes
+    with ragged windows against numpy, fixtures (incl. one that is not positive definite: minor, status, zero pattern)
+    and random ragged structures against the reference's values / the oracle"""
+    from conftest import load_golden, sym_of
+    engine.set_tuning(28, rows)
+    try:
+        if case.startswith("dense"):
+            n = int(case[5:])
+            rng = np.random.default_rng(n)
+            M = rng.standard_normal((n, n))
+            A = M @ M.T + n * np.eye(n)
+            sym = dict(n=n, nsuper=1, ssize=n, xsize=n * n, Super=np.array([0, n]), Lpi=np.array([0, n]),
+                       Lpx=np.array([0, n * n]), Ls=np.arange(n))
+            Sp = np.arange(n + 1, dtype=np.int64) * n
+            Si = np.tile(np.arange(n, dtype=np.int64), n)
+            Sx = np.ascontiguousarray(A.T).reshape(-1)
+            L = engine.SupernodalFactor(sym)
+            assert L.super_numeric(Sp, Si, Sx) == 0
+            Lg = L.Lx().reshape(n, n).T
+            assert np.all(np.triu(Lg, 1) == 0)
+            assert relerr(np.tril(Lg), np.linalg.cholesky(A)) < TOL_L
+            B = rng.standard_normal((n, 5))
+            assert relerr(L.super_ltsolve(L.super_lsolve(B)), np.linalg.solve(A, B)) < 1e-9
+            # a bad pivot inside a window: LAPACK's info, the reference's minor and zero tail
+            k = (2 * n) // 3
+            Sx2 = Sx.copy()
+            Sx2[k * n + k] = -1.0
+            assert L.super_numeric(Sp, Si, Sx2) == 1 and L.minor == k
+            Lb = L.Lx().reshape(n, n).T
+            assert np.all(Lb[:, k:] == 0)
+            assert relerr(np.tril(Lb[:, :k]), np.linalg.cholesky(A)[:, :k]) < TOL_L
+            L.close()
+        elif case[:5] in ("arrow", "block"):
+            from oracle import port
+            import test_fuzz_schedule as tf
+            kind, n = ("arrow", int(case[5:])) if case.startswith("arrow") else ("blocks", int(case[6:]))
+            g, _ = tf.build(kind, n, 6 if kind == "arrow" else 8)
+            so, mo, Lo = port.super_numeric(g, g["Sp"], g["Si"], g["Sx"])
+            L = engine.SupernodalFactor(g)
+            assert L.super_numeric(g["Sp"], g["Si"], g["Sx"]) == so == 0 and L.minor == mo
+            Lx = L.Lx()
+            for s in range(g["nsuper"]):
+                a, b = int(g["Lpx"][s]), int(g["Lpx"][s + 1])
+                nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s])
+                got, want = Lx[a:b].reshape(-1, nsrow), Lo[a:b].reshape(-1, nsrow)
+                low = np.tril(np.ones((nsrow, got.shape[0]), dtype=bool)).T
+                assert np.abs(got[low] - want[low]).max() <= 1e-10 * np.abs(Lo).max(), s
+            L.close()
+        else:
+            g = load_golden(case)
+            L = engine.SupernodalFactor(sym_of(g))
+            L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+            st = L.numeric(beta=g["beta"])
+            assert st == g["status"] and L.minor == g["minor"]
+            Lx = L.Lx()
+            assert np.array_equal(Lx == 0, g["Lx"] == 0) and relerr(Lx, g["Lx"]) < TOL_L
+            st2, Lh = L.numeric_host(beta=g["beta"])              # the copy under the factorization sees the group steps too
+            assert st2 == st and relerr(np.ascontiguousarray(Lh), g["Lx"]) < TOL_L
+            L.close()
+    finally:
+        engine.set_tuning(28, 64)

@@ -64,9 +64,13 @@ def test_tile_tables_rectangular_tiles(emu, n, cplx):
     emu.emu_check_tile_tables.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64,
                                           C.c_int, i64p]
     nb = np.zeros(1, dtype=np.int64)
-    bad = emu.emu_check_tile_tables(n, 1, np.array([0, n], dtype=np.int64), np.array([0, n], dtype=np.int64),
-                                    np.array([0, n * n], dtype=np.int64), np.arange(n, dtype=np.int64), n, n * n,
-                                    cplx, nb)
+    emu.emu_set_tuning(28, 0)        # the per-block panel chain (with panel groups a real 321-column supernode has no big update)
+    try:
+        bad = emu.emu_check_tile_tables(n, 1, np.array([0, n], dtype=np.int64), np.array([0, n], dtype=np.int64),
+                                        np.array([0, n * n], dtype=np.int64), np.arange(n, dtype=np.int64), n, n * n,
+                                        cplx, nb)
+    finally:
+        emu.emu_set_tuning(28, 64)
     assert bad == 0
     assert (nb[0] > 0) == (n >= 192 // (2 if cplx else 1) + 64)      # wide enough for a big trailing update
 
@@ -121,10 +125,12 @@ def test_tiny_launch_class(emu, name, tiny_max):
     cls = np.zeros(8, dtype=np.int64)
     emu.emu_schedule_classes.argtypes = [C.c_int64, C.c_int64, i64p, i64p, i64p, i64p, C.c_int64, C.c_int64, i64p]
     emu.emu_set_tuning(14, tiny_max)
+    emu.emu_set_tuning(28, 0)        # count the classes of the per-block chain (a panel group takes its blocks out of them)
     try:
         assert emu.emu_schedule_classes(*a, cls) == 0
     finally:
         emu.emu_set_tuning(14, 2048)
+        emu.emu_set_tuning(28, 64)
     assert cls[4] == 1
     nb = np.concatenate([np.minimum(64, w - np.arange(0, w, 64)) for w in np.diff(g["Super"])])
     if st.value == 0:
