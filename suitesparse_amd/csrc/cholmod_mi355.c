@@ -45,6 +45,8 @@ typedef struct
     int lx ;                        // MI355_REAL / MI355_COMPLEX
     int perm_set ;                  // L->Perm is on the device (cholmod_mi355_solve2)
     int multi_world ;               // > 1: the handle is partitioned over that many ranks (cholmod_mi355_register_comm)
+    int xprint_set ;                // xprint is the fingerprint of L->x as the device left it
+    uint64_t xprint ;
 } entry_t ;
 
 static entry_t *table = NULL ;
@@ -106,8 +108,58 @@ static int remember_handle (const cholmod_factor *L, mi355_factor *h, int lx)
     e->n = L->n ; e->nsuper = L->nsuper ; e->ssize = L->ssize ; e->xsize = L->xsize ; e->lx = lx ;
     e->perm_set = 0 ;
     e->multi_world = 0 ;
+    e->xprint_set = 0 ; e->xprint = 0 ;
     pthread_mutex_unlock (&table_lock) ;
     return (1) ;
+}
+
+// ---- is L->x still what the device computed? --------------------------------------------------------------------
+// The solves use the factor that is resident on the device, not L->x.  CHOLMOD's own code changes the values of a
+// supernodal L only through the hooked functions, but L->x is a public array: a caller may scale or patch it and solve.
+// The reference's GPU path has no such trap (it keeps nothing between calls).  So after every device factorization a
+// fingerprint of L->x is kept with the handle -- the bit patterns of a few thousand entries spread evenly over the array
+// plus the first and the last entry of up to 1024 supernodes -- and every solve hook compares it first: a mismatch drops
+// the device image and the CPU code solves from L->x, as it would in a build without the device.  A sample, not a proof:
+// an edit that misses every sampled entry still needs cholmod_mi355_forget (L), as INTEGRATION.md says.
+#define XPRINT_SAMPLES 4096
+static uint64_t lx_fingerprint (const cholmod_factor *L)
+{
+    const size_t E = (L->xtype == CHOLMOD_REAL) ? 1 : 2 ;
+    const size_t len = L->xsize * E ;
+    const uint64_t *x = (const uint64_t *) L->x ;
+    uint64_t hsh = 1469598103934665603ull ;
+    if (x == NULL || len == 0) return (hsh) ;
+    const size_t step = (len + XPRINT_SAMPLES - 1) / XPRINT_SAMPLES ;
+    for (size_t k = 0 ; k < len ; k += step) { hsh ^= x [k] ; hsh *= 1099511628211ull ; }
+    hsh ^= x [len - 1] ; hsh *= 1099511628211ull ;
+    const int64_t *px = (const int64_t *) L->px ;
+    if (px != NULL && L->nsuper > 0)
+    {
+        const size_t sstep = (L->nsuper + 1023) / 1024 ;
+        for (size_t sn = 0 ; sn < L->nsuper ; sn += sstep)
+        {
+            hsh ^= x [(size_t) px [sn] * E] ; hsh *= 1099511628211ull ;
+            hsh ^= x [(size_t) px [sn + 1] * E - 1] ; hsh *= 1099511628211ull ;
+        }
+    }
+    return (hsh) ;
+}
+
+// remember the fingerprint of L->x (set != 0, after the device filled it) or compare it (set == 0): TRUE if L->x is
+// still the factor the device holds (or nothing is known about it)
+static int lx_unchanged (const cholmod_factor *L, int set)
+{
+    const uint64_t now = lx_fingerprint (L) ;
+    int same = 1 ;
+    pthread_mutex_lock (&table_lock) ;
+    int k = find_locked (L) ;
+    if (k >= 0)
+    {
+        if (set) { table [k].xprint = now ; table [k].xprint_set = 1 ; }
+        else if (table [k].xprint_set) same = (table [k].xprint == now) ;
+    }
+    pthread_mutex_unlock (&table_lock) ;
+    return (same) ;
 }
 
 // multi_world of L's entry: set (world > 0) or read (world == 0)
@@ -481,6 +533,7 @@ int cholmod_mi355_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double be
     }
     count_taken (0) ;
     if (unpermuted) count_taken (3) ;
+    (void) lx_unchanged (L, 1) ;            // L->x as the device left it
     L->minor = (size_t) minor ;
     if (status == MI355_STATUS_NOT_POSDEF)
     {
@@ -511,6 +564,12 @@ int cholmod_mi355_super_solve (cholmod_factor *L, cholmod_dense *X, int lower, c
     if (L->minor < L->n) return (FALSE) ;           // not positive definite: the CPU worker sweeps what is in L->x
     mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
     if (h == NULL || multi_flag (L, 0) > 1) return (FALSE) ;     // (N ranks: every rank solves on its complete L->x)
+    if (!lx_unchanged (L, 0))
+    {
+        // somebody rewrote L->x since the factorization: the device image is not this factor any more
+        cholmod_mi355_forget (L) ;
+        return (FALSE) ;
+    }
     const int rc = lower ? mi355_super_lsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d)
                          : mi355_super_ltsolve (h, (int64_t) X->ncol, (double *) X->x, (int64_t) X->d) ;
     if (rc == MI355_INVALID)
@@ -543,6 +602,11 @@ int cholmod_mi355_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_
     if (X->nrow != L->n || X->ncol != B->ncol || X->d < L->n) return (FALSE) ;
     mi355_factor *h = handle_of (L, L->xtype == CHOLMOD_REAL ? MI355_REAL : MI355_COMPLEX) ;
     if (h == NULL || multi_flag (L, 0) > 1) return (FALSE) ;
+    if (!lx_unchanged (L, 0))
+    {
+        cholmod_mi355_forget (L) ;              // L->x was rewritten by hand: solve from it on the host
+        return (FALSE) ;
+    }
     int rc = MI355_OK ;
     if (!perm_flag (L, 0))
     {

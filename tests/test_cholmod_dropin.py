@@ -193,6 +193,35 @@ def test_hand_edited_factor_after_forget(which):
     r.close()
 
 
+@pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "lap3d_8_metis", "helm3d_6_metis"]))
+def test_hand_edited_factor_is_noticed_without_forget(which, name):
+    """the guard behind that rule (round 3): the glue keeps a fingerprint of L->x as the device left it (a few thousand
+    sampled entries) and every solve hook compares it first, so a caller who scales L->x and solves WITHOUT calling
+    cholmod_mi355_forget gets what the reference gives -- the solution of the edited factor, from the CPU code -- and the
+    stale device image is dropped; an untouched factor keeps its device solves"""
+    g = load_golden(name)
+    n = g["n"]
+    r = _cholmod(which)
+    r.load(n, g["Ap"], g["Ai"], g["Ax"], stype=g["stype"])
+    r.analyze(perm=g["Perm"], supernodal=2)
+    assert r.factorize_full() == 0
+    base = r.live_handles()
+    t0 = r.calls_taken()
+    X = r.solve(g["B"])
+    assert r.calls_taken() != t0 and r.live_handles() == base       # the device answered, the image stays
+    r.set_Lx(2.0 * r.Lx())                                             # ... and now the caller edits L->x and does not say so
+    t1 = r.calls_taken()
+    X2 = r.solve(g["B"])
+    assert r.calls_taken() == t1                                       # the CPU code answered
+    assert r.live_handles() == base - 1                                # the stale image is gone
+    assert relerr(4.0 * X2, X) < 1e-12
+    assert r.factorize_full() == 0                                     # a new factorization brings the device back
+    t2 = r.calls_taken()
+    X3 = r.solve(g["B"])
+    assert r.calls_taken() != t2 and relerr(X3, X) < 1e-12
+    r.close()
+
+
 @pytest.mark.parametrize("which,name", cases(["demo_bcsstk02", "demo_c", "lap3d_8_metis", "helm3d_6_metis", "tcov_z30lo"]))
 def test_solve2_branch_on_the_device(which, name):
     """cholmod_l_solve2's supernodal branch (cholmod_solve.c:656-717) taken over as a whole: B down once, P, both sweeps
