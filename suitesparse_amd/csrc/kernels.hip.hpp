@@ -906,12 +906,17 @@ __global__ __launch_bounds__(256) void k_potrf64(
 // the window follow in k_panel_trsm_reg.  What one phase stores the next one loads after a barrier (one workgroup = one
 // CU = one vector L1, written through).
 //------------------------------------------------------------------------------
+// (MI355_PDIAG_STAMP: defined by tools/probes/panel_diag_probe.hip only, to record clock stamps per phase)
+#ifndef MI355_PDIAG_STAMP
+#define MI355_PDIAG_STAMP(i)
+#endif
 __global__ __launch_bounds__(256) void k_panel_diag(
     const PanelGroup *__restrict__ groups, double *Lx, double *Dinv, int *info)
 {
-    // one LDS image of up to 192 rows x 64 columns: during the updates the rows of a block column from the diagonal block
-    // down; for the factorization its first 64 rows are the block (Ls) and the next 64 its inverse (Vs)
-    __shared__ double P[3 * NB][NB + 1];
+    // one LDS image of up to 256 rows x 64 columns: during the updates the earlier block columns' rows from the diagonal
+    // block down (all of them at once: (4 - b) x 64 rows of b block columns are 192, 256, 192 rows for b = 1, 2, 3); for the
+    // factorization its first 64 rows are the block (Ls) and the next 64 its inverse (Vs)
+    __shared__ double P[4 * NB][NB + 1];
     double (*Ls)[NB + 1] = P;
     double (*Vs)[NB + 1] = P + NB;
     const PanelGroup g = groups[blockIdx.x];
@@ -920,81 +925,90 @@ __global__ __launch_bounds__(256) void k_panel_diag(
     const int64_t lda = g.lda;
     double *A = Lx + g.a_off;                                   // A[i + j * lda]: row i, column j of the window
     const uint32_t l4off = (uint32_t)l4 * (uint32_t)lda;        // (lda < 2^27 for a panel group: 32-bit lane offsets)
+    // Every batch of loads below is UNCONDITIONAL (addresses clamped into the window, unwanted values dropped afterwards):
+    // a load inside a branch is waited for at the end of that branch, and the phases of this kernel are nothing but
+    // memory round trips (about 3 us each, measured: tools/probes/panel_diag_probe.hip) -- so each phase issues all its
+    // loads at once and pays one.
 #pragma unroll 1
     for (int b = 0; b < nblk; b++) {
+        MI355_PDIAG_STAMP(6 * b + 0);
         const int c0 = NB * b, nbb = min(NB, ncols - c0);
-        const int nstrips = (ncols - c0 + 15) >> 4;             // 16-row strips from row c0 down; 0 .. 3 are the diagonal block
+        const int nrow = ncols - c0;                            // rows from the diagonal block down
+        const int nrow64 = NB * (nblk - b);                     // ... in whole blocks
+        const int nstrips = (nrow + 15) >> 4;                   // 16-row strips; 0 .. 3 are the diagonal block
         // this wave's strips: w (diagonal block), w + 4, w + 8, w + 12; lane % 16 = row of the strip
         uint32_t roff[4];
         bool live[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int r = c0 + 16 * (w + 4 * i) + l15;
             live[i] = w + 4 * i < nstrips;                      // uniform over the wave
-            roff[i] = (uint32_t)min(r, ncols - 1) + l4off;      // (clamped rows are loaded, never stored)
+            roff[i] = (uint32_t)min(c0 + 16 * (w + 4 * i) + l15, ncols - 1) + l4off;
         }
-        // T in result layout: t[i][cb][gq] = entry (row of strip i, column c0 + 16 cb + lane / 16 + 4 gq)
+        // ---- T in result layout: t[i][cb][gq] = entry (row of strip i, column c0 + 16 cb + lane / 16 + 4 gq)
+        // (block column 0 has no updates: only its diagonal block is needed here, the strips below are loaded as operands later)
         v4d t[4][4];
+        if (nbb == NB) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int cb = 0; cb < 4; cb++) {
-                t[i][cb] = (v4d){0.0, 0.0, 0.0, 0.0};
-                if (live[i] && (i == 0 || b > 0))               // (block column 0 has no updates: its lower strips are loaded after the factorization)
+                for (int cb = 0; cb < 4; cb++)
 #pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int n0 = 16 * cb + 4 * gq;            // column of lane group 0; uniform
-                    if (nbb == NB) t[i][cb][gq] = (A + (int64_t)(c0 + n0) * lda)[roff[i]];
-                    else {
-                        // the last, narrower block of a window: no column beyond it is touched
-                        const int n = n0 + l4;
-                        const double v = A[(roff[i] - l4off) + (int64_t)(c0 + min(n, nbb - 1)) * lda];
+                    for (int gq = 0; gq < 4; gq++)
+                        t[i][cb][gq] = (A + (int64_t)(c0 + 16 * cb + 4 * gq) * lda)[roff[(i == 0 || b > 0) ? i : 0]];
+        } else {
+            // the last, narrower block of a window (its diagonal block is all there is): no column beyond it is touched
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int n = 16 * cb + 4 * gq + l4;
+                        const double v = A[(roff[0] - l4off) + (int64_t)(c0 + min(n, nbb - 1)) * lda];
                         t[i][cb][gq] = n < nbb ? v : 0.0;
                     }
-                }
+        }
+        // ---- the earlier block columns, rows c0 .. : chunk kc (columns 64 kc ..) -> P[kc * nrow64 + row][k]
+        // (thread: P row 64 j + tid % 64, k = tid / 64 + 4 i)
+        if (b > 0) {
+            double sreg[4][16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int pr0 = NB * j, kc = min(pr0 / nrow64, b - 1), row = (pr0 % nrow64) + (tid & 63);
+                const uint32_t voff = (uint32_t)min(row, nrow - 1) + (uint32_t)(tid >> 6) * (uint32_t)lda;
+#pragma unroll
+                for (int i = 0; i < 16; i++) sreg[j][i] = (A + c0 + (int64_t)(NB * kc + 4 * i) * lda)[voff];
             }
-        // ---- updates by the block columns before b, 64 columns of the contraction per round
-#pragma unroll 1
-        for (int kc = 0; kc < b; kc++) {
-            // rows c0 .. ncols - 1 of block column kc -> P[n][k] (thread: n = tid % 64 + 64 j, k = tid / 64 + 4 i); the first
-            // 64 rows are the operand block L(b, kc) of every product, each strip finds its own rows further down
-            {
-                const int nrow = ncols - c0;
-                double sreg[3][16];
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const uint32_t voff = (uint32_t)min((tid & 63) + NB * j, nrow - 1) + (uint32_t)(tid >> 6) * (uint32_t)lda;
-                    if (NB * j < nrow) {                        // uniform  (no break / continue in these loops: a loop that is
-                                                                // not unrolled early leaves its register arrays in scratch)
+            for (int j = 0; j < 4; j++) {
+                const bool in = NB * j < b * nrow64 && ((NB * j) % nrow64) + (tid & 63) < nrow;
 #pragma unroll
-                        for (int i = 0; i < 16; i++) sreg[j][i] = (A + c0 + (int64_t)(NB * kc + 4 * i) * lda)[voff];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const bool in = (tid & 63) + NB * j < nrow;
-                    if (NB * j < nrow) {
-#pragma unroll
-                        for (int i = 0; i < 16; i++) P[(tid & 63) + NB * j][(tid >> 6) + 4 * i] = in ? sreg[j][i] : 0.0;
-                    }
-                }
+                for (int i = 0; i < 16; i++) P[(tid & 63) + NB * j][(tid >> 6) + 4 * i] = in ? sreg[j][i] : 0.0;
             }
+        }
+        MI355_PDIAG_STAMP(6 * b + 1);
+        if (b > 0) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (live[i]) {
-                    double a[16];
+#pragma unroll 1
+                    for (int kc = 0; kc < b; kc++) {
+                        const double (*Pk)[NB + 1] = P + kc * nrow64;
+                        double a[16];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) a[q] = -P[16 * (w + 4 * i) + l15][4 * q + l4];
+                        for (int q = 0; q < 16; q++) a[q] = -Pk[16 * (w + 4 * i) + l15][4 * q + l4];
 #pragma unroll
-                    for (int q = 0; q < 16; q++)
+                        for (int q = 0; q < 16; q++)
 #pragma unroll
-                        for (int cb = 0; cb < 4; cb++)
-                            t[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(P[16 * cb + l15][4 * q + l4], a[q], t[i][cb], 0, 0, 0);
+                            for (int cb = 0; cb < 4; cb++)
+                                t[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[16 * cb + l15][4 * q + l4], a[q], t[i][cb], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
         }
+        MI355_PDIAG_STAMP(6 * b + 2);
         // ---- the diagonal block: registers -> the LDS image (identity beyond nbb), factorized and inverted there
         {
             const int i_ = 16 * w + l15;
@@ -1026,42 +1040,39 @@ __global__ __launch_bounds__(256) void k_panel_diag(
         PotrfTask pt;
         pt.a_off = g.a_off + c0 + (int64_t)c0 * lda; pt.dinv_off = groups[blockIdx.x].dinv_off[b]; pt.ls_off = 0; pt.stile0 = 0;   // (in place: g indexed by b would live in scratch)
         pt.lda = g.lda; pt.nb = nbb; pt.s = g.s; pt.col0 = g.col0 + c0; pt.k1 = 0; pt.nscol = 0; pt.urow0 = 0; pt.fuse_trsm = 0;
+        MI355_PDIAG_STAMP(6 * b + 3);
         potrf64_core(pt, Lx, Dinv, info, Ls, Vs);
-        // ---- the strips below it: X = T * W^T (W = Vs, lower; the result registers of T are the operand registers here)
+        MI355_PDIAG_STAMP(6 * b + 4);
+        // ---- the strips below it: X = T * W^T (W = Vs, lower), T back from memory in operand layout (column 4 q + lane / 16)
         if (b + 1 < nblk) {
-            const int nq = (nbb + 3) >> 2, ncb = (nbb + 15) >> 4;
+            double a[4][16];
+#pragma unroll
+            for (int i = 1; i < 4; i++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) a[i][q] = (A + (int64_t)(c0 + 4 * q) * lda)[roff[i]];
 #pragma unroll
             for (int i = 1; i < 4; i++) {
-                if (live[i]) {
                 v4d x[4];
-                double a[16];
 #pragma unroll
                 for (int cb = 0; cb < 4; cb++) x[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+                if (live[i]) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) a[q] = (A + (int64_t)(c0 + 4 * q) * lda)[roff[i]];   // operand layout: column 4 q + lane / 16
+                    for (int q = 0; q < 16; q++)
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
+                        for (int cb = 0; cb < 4; cb++)
+                            if (q <= 4 * cb + 3)                // (on or below W's diagonal; a block with rows below it is full)
+                                x[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[16 * cb + l15][4 * q + l4], a[i][q], x[cb], 0, 0, 0);
+                    if (c0 + 16 * (w + 4 * i) + l15 < ncols) {
 #pragma unroll
-                    for (int cb = 0; cb < 4; cb++) {
-                        if (q > 4 * cb + 3) continue;            // above W's diagonal
-                        if (q < nq && cb < ncb)                  // (uniform) inside the block
-                            x[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[16 * cb + l15][4 * q + l4], a[q], x[cb], 0, 0, 0);
+                        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                            for (int gq = 0; gq < 4; gq++) (A + (int64_t)(c0 + 16 * cb + 4 * gq) * lda)[roff[i]] = x[cb][gq];
                     }
-                }
-                const int r = c0 + 16 * (w + 4 * i) + l15;
-                if (r < ncols) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; cb++)
-#pragma unroll
-                        for (int gq = 0; gq < 4; gq++) {
-                            const int n = 16 * cb + l4 + 4 * gq;
-                            if (n < nbb) A[r + (int64_t)(c0 + n) * lda] = x[cb][gq];
-                        }
-                }
                 }
             }
             __syncthreads();
         }
+        MI355_PDIAG_STAMP(6 * b + 5);
     }
 }
 

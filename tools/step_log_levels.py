@@ -8,11 +8,13 @@ for line in open(sys.argv[1]):
     ms = float(d["ms"]); L = int(d["level"])
     if w[0] == "potrf":
         k, n = "potrf", int(d["count"])
+    elif w[0] in ("pdiag", "ptrsm"):
+        k, n = w[0], int(d["ntiles"])
     else:
         k = ("g128" if d["big"] == "1" else "g64") + {"0": "_upd", "1": "_trail", "2": "_trsm"}[d["mode"]]
         n = int(d["ntiles"])
     e = lv[L][k]; e[0] += 1; e[1] += ms; e[2] = max(e[2], n)
-kinds = ["potrf", "g64_trsm", "g64_trail", "g128_trail", "g64_upd", "g128_upd", "g128_trsm"]
+kinds = ["potrf", "pdiag", "ptrsm", "g64_trsm", "g64_trail", "g128_trail", "g64_upd", "g128_upd", "g128_trsm"]
 print("level " + " ".join(f"{k:>22s}" for k in kinds) + "   total ms")
 tot = 0
 for L in sorted(lv):
