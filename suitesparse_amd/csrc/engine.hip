@@ -1742,6 +1742,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                         else if (cplx) MI355_WIDE((k_solve_fwd_wide<2, 2, WIDE_THREADS>));
                         else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_fwd_wide<1, 2, WIDE_THREADS>));
                         else if (big) MI355_WIDE_T((k_solve_fwd_wide<1, 4, 1024>), 1024);
+                        else if (tuning().solve_wide_ring >= 3) MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS, 4, 3>));
                         else MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS>));
                     }
             } else {
@@ -2179,6 +2180,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 26) tuning().fuse_potrf = value ? 1 : 0;
     else if (key == 27) tuning().deterministic = value ? 1 : 0;
     else if (key == 28) tuning().panel_group = std::max(0, value);
+    else if (key == 29) tuning().solve_wide_ring = value >= 3 ? 3 : 2;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

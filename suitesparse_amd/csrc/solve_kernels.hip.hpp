@@ -1047,7 +1047,7 @@ __device__ __forceinline__ double keep_if(double v, bool keep)
     return v;
 }
 
-template <int E, int KB, int NT, int NJB = 4 * E>
+template <int E, int KB, int NT, int NJB = 4 * E, int RING = 2 /* register sets of L in flight per wave: 2 or 3 */>
 __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     const SolveGroupUpd *__restrict__ tasks, const SolveRange *__restrict__ work, const int32_t *__restrict__ wg_first,
     const double *__restrict__ Lx, const int32_t *__restrict__ Ls, double *__restrict__ Y, int64_t ldr,
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     const int nslab = (rows_run + 15) >> 4;
     const int nmine = nslab > w ? (nslab - w + NW - 1) / NW : 0;  // slabs w, w + NW, ...
     const int nch = nmine * ncq;
-    double a0[QC * E], a1[QC * E];
+    double a0[QC * E], a1[QC * E], a2[QC * E];
     // chunk ch = (slab si, k-steps [QC cc, QC cc + QC)): this lane's entries L[row][4 q + lane/16]
     auto chunk_ptr = [&](int ch, int &q0) -> const double * {
         const int si = ch / ncq;
@@ -1100,6 +1100,11 @@ __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
         const double *b1 = chunk_ptr(nch > 1 ? 1 : 0, q0);
 #pragma unroll
         for (int qq = 0; qq < QC; qq++) load1(a1, b1, q0, qq);
+        if constexpr (RING == 3) {
+            const double *b2 = chunk_ptr(nch > 2 ? 2 : 0, q0);
+#pragma unroll
+            for (int qq = 0; qq < QC; qq++) load1(a2, b2, q0, qq);
+        }
     }
     {
         // x1 of the task, zero beyond its columns (up to the end of the last chunk) and beyond the right-hand sides;
@@ -1126,12 +1131,12 @@ __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
     v4d P[NJB], Q[E == 2 ? NJB : 1];
 #pragma unroll
     for (int jb = 0; jb < NJB; jb++) { P[jb] = (v4d){0.0, 0.0, 0.0, 0.0}; if constexpr (E == 2) Q[jb] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-    // chunk ch from register set a; with AGAIN its registers are re-loaded for chunk ch + 2 as they are consumed
+    // chunk ch from register set a; with AGAIN its registers are re-loaded for chunk ch + RING as they are consumed
     auto run_chunk = [&](double (&a)[QC * E], int ch, auto again_tag) {
         constexpr bool AGAIN = decltype(again_tag)::value;
         const int si = ch / ncq, cc = ch - si * ncq;
         int q2 = 0;
-        const double *__restrict__ p2 = AGAIN ? chunk_ptr(ch + 2, q2) : nullptr;
+        const double *__restrict__ p2 = AGAIN ? chunk_ptr(ch + RING, q2) : nullptr;
         const double *__restrict__ xs = &Xs[l15][4 * cc * QC + l4];
         // 8 waves: the x1 operands of k-step qq + 1 are read from LDS while the products of k-step qq run (16 waves have
         // no registers to spare for that, and four waves per SIMD to cover the read)
@@ -1183,10 +1188,15 @@ __global__ __launch_bounds__(NT) void k_solve_fwd_wide(
             }
         }
     };
-    for (int ch = 0; ch < nch; ch += 2) {
-        if (ch + 2 < nch) run_chunk(a0, ch, std::true_type{}); else run_chunk(a0, ch, std::false_type{});
+    for (int ch = 0; ch < nch; ch += RING) {
+        if (ch + RING < nch) run_chunk(a0, ch, std::true_type{}); else run_chunk(a0, ch, std::false_type{});
         if (ch + 1 < nch) {
-            if (ch + 3 < nch) run_chunk(a1, ch + 1, std::true_type{}); else run_chunk(a1, ch + 1, std::false_type{});
+            if (ch + 1 + RING < nch) run_chunk(a1, ch + 1, std::true_type{}); else run_chunk(a1, ch + 1, std::false_type{});
+        }
+        if constexpr (RING == 3) {
+            if (ch + 2 < nch) {
+                if (ch + 2 + RING < nch) run_chunk(a2, ch + 2, std::true_type{}); else run_chunk(a2, ch + 2, std::false_type{});
+            }
         }
     }
     __syncthreads();                                              // the next segment overwrites Xs and rows_s
@@ -1470,7 +1480,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_panel_trsm_r
                     }
             }
             if (b == c && ok) {
-                // X_c is final
+                // X_c is final.  (Tried: all stores at the end of the kernel, so that no wait in the chain has to cover
+                // them -- 152 -> 178 us per launch at 150^3, the registers it costs spill.)
                 const int nbc = min(NB, ncols - NB * c);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {

@@ -547,3 +547,10 @@ def test_panel_groups_through_the_abi(engine, case, rows):
     source) on small cases -- the body of the GPU test of the same name"""
     import test_gpu_parity as tp
     tp.test_panel_groups(engine, case, rows)
+
+
+@pytest.mark.parametrize("n0,n1,nrhs,wgs", [(300, 100, 20, 256), (600, 130, 33, 3)])
+def test_wide_forward_sweep_with_three_register_sets_through_the_abi(engine, n0, n1, nrhs, wgs):
+    """tuning key 29 = 3 (k_solve_fwd_wide with a ring of three register sets) from its own source on the CPU"""
+    import test_gpu_parity as t
+    t.test_wide_forward_sweep_with_three_register_sets(engine, n0, n1, nrhs, wgs)

@@ -1011,3 +1011,14 @@ def test_panel_groups(engine, case, rows):
             L.close()
     finally:
         engine.set_tuning(28, 64)
+
+
+@pytest.mark.parametrize("n0,n1,nrhs,wgs", [(600, 150, 70, 256), (300, 200, 20, 3), (1500, 400, 33, 5)])
+def test_wide_forward_sweep_with_three_register_sets(engine, n0, n1, nrhs, wgs):
+    """tuning key 29 = 3: the forward wide kernel keeps three chunks of L in flight per wave instead of two (a deeper ring
+    for the memory latency under load); same cases, same answers"""
+    engine.set_tuning(29, 3)
+    try:
+        test_wide_multi_rhs_sweeps(engine, False, n0, n1, nrhs, wgs)
+    finally:
+        engine.set_tuning(29, 2)
