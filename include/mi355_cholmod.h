@@ -437,7 +437,13 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * one descendant per ancestor, so every entry of L receives its additions in one fixed order and two factorizations of the
  * same matrix give identical bits, as the reference's sequential loop over the descendants does (the default adds with FP64
  * atomics in whatever order the workgroups arrive: last bits differ from run to run); costs as many launch groups per level
- * as the busiest ancestor has descendants on it; keys 3 and 6: retired.  The values are process-wide and read when a factor is created. */
+ * as the busiest ancestor has descendants on it; key 28: panel groups (default 64; 0 = off): a real factor's panel chain is
+ * taken 256 columns at a time -- one workgroup factorizes the diagonal window (k_panel_diag), one launch solves the rows
+ * below it against the whole window -- three launches per 256 columns instead of thirteen (150^3: - 2.8 % of the time);
+ * the value is the rows of a panel per workgroup of that second launch: 64 or 128 = k_panel_trsm_reg (the rows in
+ * registers), 16 or 32 = k_panel_trsm (the rows in LDS; slower, kept for comparison); key 29: register sets of L in flight
+ * per wave of the forward wide sweep, 2 (default) or 3 (measured the same); keys 3 and 6: retired.  The values are
+ * process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 
 #ifdef __cplusplus
