@@ -746,6 +746,7 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
                 const Step &st = dsc.steps[si];
                 for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                     if (st.kind == STEP_POTRF) { mark(dsc.potrf[(size_t)ti].a_off, (int64_t)si); continue; }
+                    if (st.kind == STEP_PDIAG || st.kind == STEP_PTRSM) { mark(dsc.pgroups[(size_t)ti].a_off, (int64_t)si); continue; }
                     const GemmTask &t = dsc.gemm[(size_t)ti];
                     mark(t.a_off, (int64_t)si);
                     if (t.mode != GEMM_OVERWRITE) mark(t.b_off, (int64_t)si);

@@ -327,7 +327,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
         // panel groups: a window of the first nested width (4 blocks) with at least two blocks is factorized by one
         // STEP_PDIAG + STEP_PTRSM pair at the iteration of its first block
         const int64_t GW = (int64_t)SOLVE_GROUP * NB;
-        const bool pg_on = tuning().panel_group > 0 && !S.cplx && !dist && !tuning().lookahead && W.size() > 1 && W[1] == GW &&
+        const bool pg_on = tuning().panel_group > 0 && !S.cplx && !tuning().lookahead && W.size() > 1 && W[1] == GW && (!dist || WB % GW == 0) &&
                            nsrow < (1 << 27);       // (the kernels add 32-bit lane offsets of up to 4 * nsrow entries to uniform bases)
         for (int64_t j = 0; j < ncol_eff; j += NB, it++) {
             const int64_t nb = std::min<int64_t>(NB, ncol_eff - j);
@@ -337,8 +337,9 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
             const int64_t w0 = (j / GW) * GW, w1 = std::min<int64_t>(w0 + GW, ncol_eff);
             const bool grouped = pg_on && w1 - w0 > NB;
             const size_t it0 = it - (size_t)((j - w0) / NB);
+            const bool own_w = !dist || owner(s, j / WB) == dist->rank;     // (a window lies inside one outer block: one owner)
             if (grouped) {
-                if (j == w0) {
+                if (j == w0 && own_w) {
                     LevelSteps::Group G;
                     G.g.a_off = psx + w0 + w0 * nsrow;
                     for (int b = 0; b < 4; b++) { G.g.dinv_off[b] = -1; G.blk[b] = 0; }
@@ -346,7 +347,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     G.g.col0 = (int32_t)w0; G.g.below = (int32_t)(nsrow - w1); G.g.pad = 0;
                     L[lev].pgroup[it0].push_back(G);
                 }
-                L[lev].pgroup[it0].back().blk[(size_t)((j - w0) / NB)] = L[lev].potrf[it].size();
+                if (own_w) L[lev].pgroup[it0].back().blk[(size_t)((j - w0) / NB)] = L[lev].potrf[it].size();
                 grouped_blocks.insert(psx + j + j * nsrow);
             }
             PotrfTask pt;
@@ -377,7 +378,8 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     bp.root = owner(s, j / WB); bp.s = (int32_t)s;
                     bp.mine = bp.root == dist->rank ? 1 : 0;
                     bp.last = block_end ? 1 : 0;
-                    L[lev].bcast[it].push_back(bp);
+                    // (a panel group finishes its window -- POTRFs, the rows below -- at the iteration of its first block)
+                    L[lev].bcast[grouped ? it0 : it].push_back(bp);
                 }
             }
             if (below <= 0) continue;
@@ -399,7 +401,7 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                 const int64_t K = e - b0, Nn = enc_end - e;
                 if (grouped && lvl == 0) {
                     // the K = 64 update inside the window: part of the group's kernels (same flops)
-                    out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
+                    if (own) out.flops_panel += ((double)Nn * Nn + 2.0 * (double)(below - Nn) * Nn) * (double)K;
                     break;
                 }
                 if (dist && lvl + 1 == W.size()) {
@@ -410,7 +412,8 @@ void build_schedule(const Symbolic &S, int64_t s_limit, int64_t nscol2_limit, Sc
                     for (int64_t c0 = e; c0 < ncol_eff; c0 += WB) {
                         const int64_t c1 = std::min<int64_t>(c0 + WB, ncol_eff);
                         if (owner(s, c0 / WB) != dist->rank) continue;
-                        auto &dst = (tuning().dist_lookahead && c0 > e) ? L[lev].rest[it] : L[lev].trail[it];
+                        const size_t itq = grouped ? it0 : it;
+                        auto &dst = (tuning().dist_lookahead && c0 > e) ? L[lev].rest[itq] : L[lev].trail[itq];
                         dst.push_back(make_gemm(
                             psx + c0 + b0 * nsrow, psx + c0 + b0 * nsrow,
                             psx + c0 + c0 * nsrow, -1, nsrow, nsrow, nsrow,
@@ -1076,13 +1079,22 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         for (int64_t si = b.step; si < b.wait_step; si++) {
             const Step &st = sc.steps[(size_t)si];
             if (st.kind == STEP_POTRF) {
-                for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                // (the last nfused tasks of a step have no launch here: a panel group or a trailing update factorizes them)
+                for (int64_t ti = st.first; ti < st.first + st.count - st.nfused; ti++) {
                     const PotrfTask &t = sc.potrf[(size_t)ti];
                     if (hits(t.a_off, t.nb, t.nb, t.lda)) return bad("broadcast in flight: a diagonal block being factorized", (int64_t)i);
                 }
                 continue;
             }
-            if (st.kind != STEP_GEMM) return bad("broadcast in flight over a panel group", (int64_t)i);   // (never built together)
+            if (st.kind != STEP_GEMM) {
+                // a panel group reads and writes its own window and the rows below it: whole columns col0 .. col0 + ncols - 1
+                for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
+                    const PanelGroup &g = sc.pgroups[(size_t)ti];
+                    const int64_t lo_w = S.Lpx[g.s] + (int64_t)g.col0 * g.lda, hi_w = lo_w + (int64_t)g.ncols * g.lda;
+                    if (lo_w < b.lo + b.count && hi_w > b.lo) return bad("broadcast in flight: the window of a panel group", (int64_t)i);
+                }
+                continue;
+            }
             for (int64_t ti = st.first; ti < st.first + st.count; ti++) {
                 const GemmTask &t = sc.gemm[(size_t)ti];
                 if (!b.mine && hits(t.a_off, t.M, t.K, t.lda)) return bad("broadcast in flight: A operand of a task", (int64_t)i);

@@ -138,6 +138,10 @@ def check_own_columns(g, owner, rank, Lx, Lo, tol=1e-10):
     # ob = (first nested width, block width): blocks of the top travel in pieces (tuning key 17) while their chain runs
     ("lap3d", 12, 2, True, False, (128, 256), True, 1), ("lap3d", 14, 3, True, False, (128, 256), True, 1),
     ("lap3d", 12, 2, True, False, (128, 256), False, 0), ("lap3d", 12, 2, True, True, (128, 256), True, 1),
+    # the default first width (256): the owner of a block runs its windows as panel groups (k_panel_diag, k_panel_trsm_reg;
+    # tuning key 28) and a piece leaves when its window is done -- top separators of 324 and 400 columns
+    ("lap3d", 18, 2, True, False, (256, 512), True, 1), ("lap3d", 20, 3, True, False, (256, 1024), False, 1),
+    ("lap3d", 18, 2, True, True, (256, 512), True, 1), ("lap3d", 18, 3, True, False, (256, 512), True, 0),
     ])
 def test_numeric_and_solve_multi_with_threads_as_ranks(engine, kind, size, world, dist_top, spoil, ob, defer, lookahead):
     """defer: the transport completes every collective at the LATEST point the engine's ordering allows (a blocking one
@@ -333,7 +337,8 @@ class IdBox:
     ("helm", 4, 2, True, False, 64, 0), ("lap3d", 12, 2, True, False, (128, 256), 0), ("lap2d", 16, 4, True, False, 64, 0),
     ("bordered", 0, 3, True, False, (128, 256), 0),
     ("lap3d", 6, 3, True, False, 64, 1), ("lap3d", 4, 2, True, True, 64, 1), ("helm", 4, 2, True, False, 64, 1),
-    ("lap3d", 12, 2, True, False, (128, 256), 1), ("lap3d", 9, 4, True, False, 64, 1)])
+    ("lap3d", 12, 2, True, False, (128, 256), 1), ("lap3d", 9, 4, True, False, 64, 1),
+    ("lap3d", 18, 2, True, False, (256, 512), 1), ("lap3d", 18, 3, True, False, (256, 512), 0)])
 def test_stream_ordered_driver_with_the_rccl_stand_in(engine, kind, size, world, dist_top, spoil, ob, channel):
     """The RCCL path of the driver -- mi355_comm_create_rccl, collectives ENQUEUED on the communicator's stream, compute
     and communication ordered by events only, the status agreement through a device buffer -- with the stand-in for
