@@ -16,7 +16,8 @@ i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 GEMM_TFLOPS = 58.0        # big-update rate on one GPU (55-65 TFLOP/s at K >= 600)
-STEP_US = 135.0           # one 64-column panel step (POTRF + TRSM + inner update), latency-bound
+STEP_US = 77.0            # one 64-column panel step, latency-bound: a quarter of a panel group (k_panel_diag 154 us + k_panel_trsm_reg
+                          # 152 us per 256 columns, profiles/r03_lap3d150_kernel_stats.txt; 135 us with the per-block chain of rounds 1 and 2)
 XGMI_GBS = 300.0          # what one rank moves per second in a ring all-reduce / a broadcast (a few links in use)
 
 
