@@ -400,6 +400,10 @@ __device__ __forceinline__ void potrf64_block(
 // supernode is two dependent launches per 64 columns (TRSM, trailing update) instead of three, and the 35-45 us of the
 // single-workgroup POTRF run beside the other tiles of the update instead of after them.  potrf / dinv_w / info: the
 // schedule's POTRF tasks, the block inverses (written here; `Dinv` is the read-only view of the TRSM tasks), LAPACK's info.
+#ifndef G128_RMW
+#define G128_RMW 4          // 16-row blocks per read-modify-write batch of the DIRECT_SUB epilogue (1, 2 or 4; measured at 150^3 and
+                            // elasticity 80^3: 4 is 0.5 - 0.7 % faster than 1 or 2 although its 64 values in flight spill 92 bytes)
+#endif
 template <bool CPLX>
 __global__ __launch_bounds__(256, 2) void k_gemm128(
     const GemmTask *__restrict__ tasks, const Schedule::TileEntry *__restrict__ tile_tab, double *__restrict__ Lx,
@@ -590,21 +594,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(
     if (mode == GEMM_DIRECT_SUB) {
         // read-modify-write in batches of 16: all loads of a batch are issued before the first use, so
         // the wave waits for memory once per batch instead of once per element
+        // (G128_RMW row blocks of 16 per batch: the staging registers of the main loop are free by now, and every batch
+        // is one memory round trip of the tile's epilogue)
 #pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
+        for (int mb = 0; mb < 4; mb += G128_RMW) {
             if (skip_mma) break;                 // (a wave that only came along for the fused POTRF below)
-            const int m = m0 + wm * 64 + mi * 16 + l15;
-            double cv[16];
+            double cv[G128_RMW][16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
-                const bool ok = (m < M) && (n < N) && lower(m, n);
-                cv[q] = C[ok ? (m + (int64_t)n * ldc) : 0];
+            for (int u = 0; u < G128_RMW; u++) {
+                const int m = m0 + wm * 64 + (mb + u) * 16 + l15;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
+                    const bool ok = (m < M) && (n < N) && lower(m, n);
+                    cv[u][q] = C[ok ? (m + (int64_t)n * ldc) : 0];
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
-                if ((m < M) && (n < N) && lower(m, n)) C[m + (int64_t)n * ldc] = cv[q] - acc[q >> 2][mi][q & 3];
+            for (int u = 0; u < G128_RMW; u++) {
+                const int m = m0 + wm * 64 + (mb + u) * 16 + l15;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int n = n0 + wn * 64 + (q >> 2) * 16 + l4 + 4 * (q & 3);
+                    if ((m < M) && (n < N) && lower(m, n)) C[m + (int64_t)n * ldc] = cv[u][q] - acc[q >> 2][mb + u][q & 3];
+                }
             }
         }
         if (stamps && tid == 0) {

@@ -53,3 +53,27 @@ def test_rcond_without_allocation_matches_rcond(engine):
         bad.rcond_noalloc(0)
     for L in (big, small, cplx, bad):
         L.close()
+
+
+@pytest.mark.parametrize("name", ["lap3d_8_metis", "helm3d_6_metis", "demo_bcsstk02", "tcov_ex5lo"])
+def test_rcond_without_allocation_against_the_reference_definition(engine, name):
+    """... and directly against what cholmod_rcond computes from the REFERENCE's factor of the same matrix (the fixture's
+    L->x): for an LL' factor (min_j L_jj / max_j L_jj)^2 over the diagonal of every supernode
+    (CHOLMOD/Cholesky/cholmod_rcond.c:51-110, the supernodal branch) -- not only against the sibling entry point"""
+    import torch
+    g = load_golden(name)
+    cplx = g["xtype"] == 2
+    L = engine.SupernodalFactor(sym_of(g), xtype=2 if cplx else 1)
+    L.set_matrix(g["Sp"], g["Si"], g["Sx"])
+    assert L.numeric(beta=g["beta"]) == 0
+    d = []
+    for s in range(g["nsuper"]):
+        nscol = int(g["Super"][s + 1] - g["Super"][s]); nsrow = int(g["Lpi"][s + 1] - g["Lpi"][s]); px = int(g["Lpx"][s])
+        d.append(np.real(g["Lx"][px + np.arange(nscol) * (nsrow + 1)]))
+    d = np.concatenate(d)
+    want = (d.min() / d.max()) ** 2
+    out = torch.full((1,), -7.0, dtype=torch.float64, device="cuda")
+    L.rcond_noalloc(out.data_ptr())
+    got = float(out[0].item())
+    assert abs(got - want) <= 1e-10 * want, (got, want)
+    L.close()
