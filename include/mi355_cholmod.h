@@ -442,7 +442,11 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * below it against the whole window -- three launches per 256 columns instead of thirteen (150^3: - 2.8 % of the time);
  * the value is the rows of a panel per workgroup of that second launch: 64 or 128 = k_panel_trsm_reg (the rows in
  * registers), 16 or 32 = k_panel_trsm (the rows in LDS; slower, kept for comparison); key 29: register sets of L in flight
- * per wave of the forward wide sweep, 2 (default) or 3 (measured the same); keys 3 and 6: retired.  The values are
+ * per wave of the forward wide sweep, 2 (default) or 3 (measured the same); key 30: look-ahead of the sweeps with several
+ * right-hand sides (default 0 = off; 12 = on): inside a supernode of several solve groups the update of the rows beyond the
+ * next group runs on a second stream beside the next group's kernel; the value is the number of CUs such a step leaves
+ * to that kernel (read when the solve lists are built, at a factor's first solve).  Measured: - 2 .. 4 % for a real factor
+ * with 64 right-hand sides, + 4 .. 5 % for a complex one or for 8 right-hand sides; keys 3 and 6: retired.  The values are
  * process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 

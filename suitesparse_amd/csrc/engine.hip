@@ -107,6 +107,7 @@ struct mi355_factor_s {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;             // look-ahead: the far part of the outermost trailing updates (STEP_SIDE)
     std::vector<hipEvent_t> side_ev;        // fork/join events, reused by every factorization
+    std::vector<hipEvent_t> solve_ev;       // look-ahead of the sweeps (tuning key 30): 4 + 4 + 1 events, reused by every solve
     int xtype = MI355_REAL;
     int E = 1;                  // doubles per entry: 1 real, 2 complex (interleaved)
     // host copy of the symbolic factor
@@ -822,6 +823,7 @@ int mi355_factor_free(mi355_factor *F)
     if (F->side) { (void)hipStreamSynchronize(F->side); (void)hipStreamDestroy(F->side); }
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
     for (hipEvent_t ev : F->side_ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : F->solve_ev) (void)hipEventDestroy(ev);
     if (F->copy_stream) { (void)hipStreamSynchronize(F->copy_stream); (void)hipStreamDestroy(F->copy_stream); }
     for (hipStream_t st : F->lane_stream) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *p : F->lane_pin) (void)hipHostFree(p);
@@ -1671,10 +1673,52 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         // many right-hand sides, grouped: k_solve_group_mma per SOLVE_GROUP blocks + the MFMA updates of the rows below
         { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
         const std::vector<SolveStep> &gs = DS.ssched.steps;
+        // Look-ahead (tuning key 30; off by default -- measured below).  The top supernodes are chains of single-group steps: group kernel (a handful of
+        // workgroups, ~20 us of dependent products) -> update of every row below (the whole chip) -> next group ...  Only the
+        // first SOLVE_GROUP tiles of that update are rows of the NEXT group; the rest is needed two groups later at the
+        // earliest.  The schedule splits such a step (st.wsplit): the near tiles on the per-block lists (~10 us on a handful of
+        // tiles), the rows beyond on the wide lists.  Within a run of consecutive groups of one supernode the near part stays
+        // on F->stream (high priority) with the group kernels, and the far part goes to F->side, ordered by events:
+        //   forward   G(p) -> near(p) -> G(p+1) ...   far(p) after G(p);  G(p+2) after far(p)
+        //   backward  near(p) -> G(p) -> near(p+1) .. far(p) after G(p-2) (the run's start for p = 1);  G(p) after far(p)
+        // (p = position in the run; backward runs go up the supernode, and their first step stays on one stream).  Every add
+        // into X is atomic in these kernels, so the two parts of a step may overlap; a step outside the run joins the streams.
+        // Measured (profiles/r03_solve_look_ahead.txt): the far parts do run beside the next group, but every link of the chain
+        // -- group kernel ~20 us, near part ~15 us, whole update 20 .. 45 us -- is a latency floor of its own, and the events
+        // add ~10 us between a group kernel and its near part: 150^3 with 64 right-hand sides 74.2 -> 72.3 ms, elasticity
+        // 51.0 -> 49.0 ms, but Helmholtz 54.1 -> 57.0 ms and 8 right-hand sides 46.7 -> 48.6 ms.  Hence off.
+        const bool look = tuning().solve_lookahead > 0 && tuning().solve_wide && DS.ssched.kmax > 0 && F->side != nullptr;
+        if (look)
+            while (F->solve_ev.size() < 9) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                F->solve_ev.push_back(ev);
+            }
+        hipEvent_t *const evG = F->solve_ev.data(), *const evU = evG + 4;     // (only touched when look)
+        int run = -1;                       // position of the previous step in its run; -1: it was not a split step
+        int64_t run_next = -1;              // a_off of the group that continues the run
+        int32_t run_lda = 0;
+        bool side_busy = false;             // forward: far parts on F->side that F->stream has not waited for
+        int side_last = 0;
         for (size_t ii = 0; ii < gs.size(); ii++) {
             const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
             if (st.gcount <= 0) continue;
             if (st.gcount > 0x7fffffffLL || st.stiles > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve tiles in one step");
+            int pos = -1;
+            if (look && st.wsplit > 0) {
+                // consecutive groups of one supernode: same leading dimension, diagonal entries ncols * (lda + 1) apart
+                const SolveGroupTask &hg = DS.ssched.groups[(size_t)st.gfirst];
+                const int64_t len = (int64_t)hg.ncols * ((int64_t)hg.lda + 1);
+                const bool cont = run >= 0 && hg.lda == run_lda && (lower ? hg.a_off : hg.a_off + len) == run_next;
+                pos = cont ? run + 1 : 0;
+                run_lda = hg.lda;
+                run_next = lower ? hg.a_off + len : hg.a_off;
+            }
+            if (pos <= 0 && side_busy) {
+                HIP_TRY(hipStreamWaitEvent(F->stream, evU[side_last], 0));
+                side_busy = false;
+            }
+            run = pos;
             auto group_kernel = [&]() {
                 // a step of one-block groups only (the leaf levels: 10^5 groups of a few columns) takes 64 real columns of Y per
                 // workgroup instead of 16: a quarter of the workgroups, each with four times the products of its one step
@@ -1718,18 +1762,14 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             int64_t wt64 = 0;                           // 64-row tiles of the step's wide tasks
             if (wide) for (int64_t u = 0; u < st.wcount; u++) wt64 += (DS.ssched.wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
             if (wide && st.wrcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
-            if (lower) {
-                group_kernel();
-                if (ptiles > 0)
-                    for (int j0 = 0; j0 < nrr; j0 += 64)
-                        hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
-                                           ptasks, ptmap, ptiles, group, F->Lx.p, F->dLs.p, X, d, nrr, j0);
-                if (wide && st.wrcount > 0)
-                    for (int j0 = 0; j0 < nrr; j0 += wnj) {
-#define MI355_WIDE_T(K, NT) hipLaunchKernelGGL(K, dim3((unsigned)st.wgcount), dim3(NT), 0, F->stream, \
-                                         DS.swtasks.p + st.wfirst, DS.swranges.p + st.wrfirst, DS.swwg.p + st.wgfirst, \
+            // workgroups [w0, w0 + wn) of the step's wide launch on stream wq
+#define MI355_WIDE_T(K, NT) hipLaunchKernelGGL(K, dim3((unsigned)wn), dim3(NT), 0, wq, \
+                                         DS.swtasks.p + st.wfirst, DS.swranges.p + st.wrfirst, DS.swwg.p + st.wgfirst + w0, \
                                          F->Lx.p, F->dLs.p, X, d, nrr, j0)
 #define MI355_WIDE(K) MI355_WIDE_T(K, WIDE_THREADS)
+            auto wide_fwd = [&](hipStream_t wq, int64_t w0, int64_t wn) {
+                if (wide && st.wrcount > 0 && wn > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += wnj) {
                         // real factor: 16 waves per workgroup (4 per SIMD: the kernel fits 128 registers) once the shares are
                         // long enough to give every wave a slab (tuning key 25)
                         const bool big = tuning().solve_wide_1024 && st.wgcount > 0 && wt64 >= 4 * st.wgcount;
@@ -1745,10 +1785,9 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                         else if (tuning().solve_wide_ring >= 3) MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS, 4, 3>));
                         else MI355_WIDE((k_solve_fwd_wide<1, 4, WIDE_THREADS>));
                     }
-            } else {
-                const int64_t prcount = wide ? st.nrmcount : st.rmcount;
-                const SolveRange *pruns = wide ? DS.snranges_mma.p + st.nrmfirst : DS.sranges_mma.p + st.rmfirst;
-                if (wide && st.wrcount > 0)
+            };
+            auto wide_bwd = [&](hipStream_t wq, int64_t w0, int64_t wn) {
+                if (wide && st.wrcount > 0 && wn > 0)
                     for (int j0 = 0; j0 < nrr; j0 += wnj) {
                         if (few) {
                             if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2, 1>));
@@ -1758,19 +1797,49 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                         else if (cplx) MI355_WIDE((k_solve_bwd_wide<2, 2>));
                         else if (st.wmaxblk <= 2) MI355_WIDE((k_solve_bwd_wide<1, 2>));
                         else MI355_WIDE((k_solve_bwd_wide<1, 4>));
+                    }
+            };
 #undef MI355_WIDE
 #undef MI355_WIDE_T
-                    }
+            if (lower) {
+                if (pos >= 2) HIP_TRY(hipStreamWaitEvent(F->stream, evU[(pos - 2) & 3], 0));
+                group_kernel();
+                if (pos >= 0) {
+                    HIP_TRY(hipEventRecord(evG[pos & 3], F->stream));
+                    HIP_TRY(hipStreamWaitEvent(F->side, evG[pos & 3], 0));
+                    wide_fwd(F->side, 0, st.wgcount);
+                    HIP_TRY(hipEventRecord(evU[pos & 3], F->side));
+                    side_busy = true; side_last = pos & 3;
+                }
+                if (ptiles > 0)
+                    for (int j0 = 0; j0 < nrr; j0 += 64)
+                        hipLaunchKernelGGL(cplx ? k_solve_fwd_mma<2> : k_solve_fwd_mma<1>, dim3(grid), dim3(256), 0, F->stream,
+                                           ptasks, ptmap, ptiles, group, F->Lx.p, F->dLs.p, X, d, nrr, j0);
+                if (pos < 0) wide_fwd(F->stream, 0, st.wgcount);
+            } else {
+                const int64_t prcount = wide ? st.nrmcount : st.rmcount;
+                const SolveRange *pruns = wide ? DS.snranges_mma.p + st.nrmfirst : DS.sranges_mma.p + st.rmfirst;
+                if (pos >= 1) {
+                    HIP_TRY(hipStreamWaitEvent(F->side, pos >= 2 ? evG[(pos - 2) & 3] : F->solve_ev[8], 0));
+                    wide_bwd(F->side, 0, st.wgcount);
+                    HIP_TRY(hipEventRecord(evU[pos & 3], F->side));
+                } else {
+                    if (pos == 0) HIP_TRY(hipEventRecord(F->solve_ev[8], F->stream));
+                    wide_bwd(F->stream, 0, st.wgcount);
+                }
                 if (prcount > 0) {
                     if (prcount > 0x7fffffffLL) return fail(MI355_TOO_LARGE, "too many solve runs in one step");
                     for (int j0 = 0; j0 < nrr; j0 += 64)
                         hipLaunchKernelGGL(cplx ? k_solve_bwd_mma_run<2> : k_solve_bwd_mma_run<1>, dim3((unsigned)prcount),
                                            dim3(256), 0, F->stream, ptasks, pruns, F->Lx.p, F->dLs.p, X, d, nrr, j0);
                 }
+                if (pos >= 1) HIP_TRY(hipStreamWaitEvent(F->stream, evU[pos & 3], 0));
                 group_kernel();
+                if (pos >= 0) HIP_TRY(hipEventRecord(evG[pos & 3], F->stream));
             }
             HIP_TRY(hipGetLastError());
         }
+        if (side_busy) HIP_TRY(hipStreamWaitEvent(F->stream, evU[side_last], 0));
     } else if (lower) {
         for (size_t i = 0; i < steps.size(); i++) {
             const Step &st = steps[i];
@@ -2181,6 +2250,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 27) tuning().deterministic = value ? 1 : 0;
     else if (key == 28) tuning().panel_group = std::max(0, value);
     else if (key == 29) tuning().solve_wide_ring = value >= 3 ? 3 : 2;
+    else if (key == 30) tuning().solve_lookahead = std::max(0, std::min(value, 128));
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

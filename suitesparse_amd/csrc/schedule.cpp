@@ -688,7 +688,7 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
             st.nufirst = (int64_t)out.nutasks.size(); st.nucount = 0;
             st.nstiles = 0; st.ntmap_off = (int64_t)out.ntile_task.size();
             st.wfirst = (int64_t)out.wtasks.size(); st.wcount = 0;
-            st.wmaxblk = 1; st.pad2 = 0;
+            st.wmaxblk = 1; st.wsplit = 0;
             // groups: one per supernode present at the first iteration of the range
             std::vector<std::pair<int32_t, int64_t>> by_s;         // (supernode, group index), sorted by supernode
             const Step &f = *its[g0];
@@ -722,6 +722,16 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
             }
             for (int64_t gi = 0; gi < st.gcount; gi++) {
                 const SolveGroupTask &gt = out.groups[(size_t)(st.gfirst + gi)];
+                // look-ahead (tuning key 30): a step of ONE group with rows beyond the next group's is split -- the first
+                // SOLVE_GROUP tiles below the group (the next group's rows, all the next group kernel waits for) go to the
+                // per-block lists, whose kernels take ~10 us on a handful of tiles; the rows beyond stay with the wide lists
+                // and run beside the next group on a second stream
+                int32_t near_tiles = 0;
+                if (tuning().solve_lookahead > 0 && kmax > 0 && st.gcount == 1 && gt.ncols > NB && !blocks[(size_t)gi].empty()) {
+                    const PotrfTask &p0 = blocks[(size_t)gi][0];
+                    if ((int64_t)p0.lda - ((gt.x0 - p0.k1) + gt.ncols) > (int64_t)SOLVE_GROUP * SOLVE_ROWS) near_tiles = SOLVE_GROUP;
+                }
+                st.wsplit = near_tiles;
                 for (PotrfTask pt : blocks[(size_t)gi]) {
                     const int32_t gcol0 = gt.x0 - pt.k1;            // first column of the group inside s
                     pt.urow0 = gcol0 + gt.ncols;
@@ -736,11 +746,12 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                     out.tile_task.insert(out.tile_task.end(), (size_t)nt, (int32_t)st.ucount);
                     out.utasks.push_back(pt);
                     st.ucount++;
-                    if (kmax > 0 && gt.ncols <= NB) {
-                        // a group of one block: the per-block kernels, on the lists of the wide path
+                    if (kmax > 0 && (gt.ncols <= NB || near_tiles > 0)) {
+                        // a group of one block: the per-block kernels, on the lists of the wide path (a split step: its near tiles)
+                        const int64_t nn = near_tiles > 0 ? std::min<int64_t>(nt, near_tiles) : nt;
                         pt.stile0 = st.nstiles;
-                        st.nstiles += nt;
-                        out.ntile_task.insert(out.ntile_task.end(), (size_t)nt, (int32_t)st.nucount);
+                        st.nstiles += nn;
+                        out.ntile_task.insert(out.ntile_task.end(), (size_t)nn, (int32_t)st.nucount);
                         out.nutasks.push_back(pt);
                         st.nucount++;
                     }
@@ -748,7 +759,8 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                 if (kmax > 0 && gt.ncols > NB && !blocks[(size_t)gi].empty()) {
                     const PotrfTask &p0 = blocks[(size_t)gi][0];
                     const int32_t gcol0 = gt.x0 - p0.k1;
-                    const int32_t below = p0.lda - (gcol0 + gt.ncols);
+                    const int32_t skip = near_tiles * SOLVE_ROWS;       // rows of a split step that the per-block lists hold
+                    const int32_t below = p0.lda - (gcol0 + gt.ncols) - skip;
                     for (int32_t c0 = 0; below > 0 && c0 < gt.ncols; c0 += kmax) {
                         SolveGroupUpd wt;
                         wt.lda = p0.lda;
@@ -756,8 +768,8 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                         wt.x0 = gt.x0 + c0;
                         wt.nrows = below;
                         // gt.a_off = L[gcol0][gcol0]; the first row below the group is local row gcol0 + ncols
-                        wt.a_off = gt.a_off + gt.ncols + (int64_t)c0 * p0.lda;
-                        wt.ls_off = p0.ls_off + gcol0 + gt.ncols;
+                        wt.a_off = gt.a_off + gt.ncols + skip + (int64_t)c0 * p0.lda;
+                        wt.ls_off = p0.ls_off + gcol0 + gt.ncols + skip;
                         st.wmaxblk = std::max<int32_t>(st.wmaxblk, (wt.ncols + NB - 1) / NB);
                         out.wtasks.push_back(wt);
                         st.wcount++;
@@ -789,7 +801,8 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                 const int64_t run = std::min<int64_t>(16, std::max<int64_t>(1, st.nstiles / std::max(1, tuning().solve_bwd_div_mma)));
                 for (int64_t u = 0; u < st.nucount; u++) {
                     const PotrfTask &pt = out.nutasks[(size_t)(st.nufirst + u)];
-                    const int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                    int64_t nt = ((int64_t)pt.lda - pt.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+                    if (st.wsplit > 0) nt = std::min<int64_t>(nt, st.wsplit);
                     for (int64_t t0 = 0; t0 < nt; t0 += run)
                         out.nranges_mma.push_back({(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(run, nt - t0), 0});
                 }
@@ -806,7 +819,11 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                 }
                 int64_t wt64 = 0;
                 for (int64_t u = 0; u < st.wcount; u++) wt64 += (out.wtasks[(size_t)(st.wfirst + u)].nrows + 63) / 64;
-                const int64_t G = std::max<int64_t>(1, std::min<int64_t>(tuning().solve_wide_wgs, wt64));
+                // look-ahead (tuning key 30 = CUs kept free, 0 = off): a step of one group with one wide task is dealt to that many
+                // fewer workgroups, so that the next group's kernel finds CUs while this step's far rows are still being updated
+                const bool alone = st.wsplit > 0;
+                const int64_t wgs = alone ? std::max<int64_t>(8, (int64_t)tuning().solve_wide_wgs - tuning().solve_lookahead) : tuning().solve_wide_wgs;
+                const int64_t G = std::max<int64_t>(1, std::min<int64_t>(wgs, wt64));
                 st.wgfirst = (int64_t)out.wwg.size(); st.wgcount = 0;
                 if (st.wcount > 0) {
                     out.wwg.push_back(0);
@@ -1163,7 +1180,8 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
         for (int64_t u = 0; u < st.nucount; u++) {
             const PotrfTask &t = ss->nutasks[(size_t)(st.nufirst + u)];
             if (t.stile0 != tiles) return bad("solve step narrow tile prefix", (int64_t)i);
-            tiles += ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+            const int64_t all = ((int64_t)t.lda - t.urow0 + SOLVE_ROWS - 1) / SOLVE_ROWS;
+            tiles += st.wsplit > 0 ? std::min<int64_t>(all, st.wsplit) : all;       // (a split step lists its near tiles only)
         }
         if (tiles != st.nstiles) return bad("solve step narrow tile count", (int64_t)i);
         for (int64_t b = 0; b < st.nstiles; b++) {
@@ -1203,7 +1221,18 @@ std::string check_schedule_bounds(const Symbolic &S, const Schedule &sc, const S
                 if (e.tile0 != next_tile) return bad("solve wide segment order", k);
                 next_tile += e.ntiles;
             }
-        } else if (st.wrcount != 0) return bad("solve step wide runs without tasks", (int64_t)i);
+            // a split step: one group, whose wide tasks start SOLVE_GROUP tiles below it and whose per-block tasks hold exactly
+            // those tiles -- what the look-ahead's event order relies on (engine.hip, solve_dev)
+            if (st.wsplit != 0) {
+                const SolveGroupTask &gt = ss->groups[(size_t)st.gfirst];
+                if (st.wsplit != SOLVE_GROUP || st.gcount != 1 || st.nucount <= 0 || st.nstiles != st.nucount * st.wsplit) return bad("solve step split", (int64_t)i);
+                for (int64_t u = 0; u < st.wcount; u++) {
+                    const SolveGroupUpd &wt = ss->wtasks[(size_t)(st.wfirst + u)];
+                    const int64_t c0 = wt.x0 - gt.x0;
+                    if (c0 < 0 || wt.a_off != gt.a_off + gt.ncols + (int64_t)st.wsplit * SOLVE_ROWS + c0 * gt.lda) return bad("solve step split: far rows", (int64_t)i);
+                }
+            }
+        } else if (st.wrcount != 0 || st.wsplit != 0) return bad("solve step wide runs without tasks", (int64_t)i);
     }
     for (size_t i = 0; i < ss->nutasks.size(); i++) {
         const PotrfTask &t = ss->nutasks[i];

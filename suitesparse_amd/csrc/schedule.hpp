@@ -110,7 +110,11 @@ struct SolveStep {
     int64_t wrfirst, wrcount;           // segments (runs of 64-row tiles of one task) over them (in wranges; task relative to wfirst)
     int64_t wgfirst, wgcount;           // the step's workgroups: wwg[wgfirst + g] .. wwg[wgfirst + g + 1] = segments of workgroup g
                                         // (relative to wrfirst; wgcount + 1 offsets)
-    int32_t wmaxblk, pad2;              // most 64-column blocks of any wide task of the step
+    int32_t wmaxblk;                    // most 64-column blocks of any wide task of the step
+    int32_t wsplit;                     // look-ahead of the sweeps (tuning key 30): a step of ONE group split into its near rows -- the first
+                                        // wsplit (= SOLVE_GROUP) tiles below the group, i.e. the rows of the supernode's next group, listed
+                                        // per block in nutasks / ntile_task / nranges_mma -- and the rows beyond them (the wide tasks, which
+                                        // then start wsplit tiles lower); 0: the step is not split
 };
 struct SolveSchedule {
     std::vector<SolveGroupTask> groups;
@@ -278,7 +282,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax = 0 /* 256 real, 128 complex; 0: no wide lists */);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; int panel_group = 64; int solve_wide_ring = 2; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; int panel_group = 64; int solve_wide_ring = 2; int solve_lookahead = 0; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

@@ -554,3 +554,11 @@ def test_wide_forward_sweep_with_three_register_sets_through_the_abi(engine, n0,
     """tuning key 29 = 3 (k_solve_fwd_wide with a ring of three register sets) from its own source on the CPU"""
     import test_gpu_parity as t
     t.test_wide_forward_sweep_with_three_register_sets(engine, n0, n1, nrhs, wgs)
+
+
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,keep", [(False, 1100, 200, 9, 12), (True, 600, 130, 7, 12)])
+def test_sweeps_with_look_ahead_through_the_abi(engine, cplx, n0, n1, nrhs, keep):
+    """tuning key 30: the split of a step's wide launch into its first workgroups and the rest, on two streams (the stand-in
+    runs a stream's work at once, so this checks the split itself -- every workgroup exactly once -- and the event calls)"""
+    import test_gpu_parity as t
+    t.test_sweeps_with_look_ahead(engine, cplx, n0, n1, nrhs, keep)

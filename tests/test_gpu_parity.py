@@ -1022,3 +1022,17 @@ def test_wide_forward_sweep_with_three_register_sets(engine, n0, n1, nrhs, wgs):
         test_wide_multi_rhs_sweeps(engine, False, n0, n1, nrhs, wgs)
     finally:
         engine.set_tuning(29, 2)
+
+
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,keep", [(False, 1500, 400, 9, 12), (False, 2700, 300, 70, 12), (True, 1100, 200, 7, 12), (True, 900, 330, 40, 40),
+                                                  (False, 1500, 400, 33, 0)])
+def test_sweeps_with_look_ahead(engine, cplx, n0, n1, nrhs, keep):
+    """tuning key 30 (12 = on; off by default): the steps of a supernode of several solve groups run on two streams -- the group kernels and the
+    rows of the next group on one, the rows beyond on the other, ordered by events (engine.hip, solve_dev).  A first supernode
+    of 5 .. 11 groups (more than the ring of four events holds) with scattered rows of a second one below it; `keep` = CUs
+    kept free (0 = off: the lists are not split); same answers as the oracle's sweeps, on the factor the same test builds"""
+    engine.set_tuning(30, keep)
+    try:
+        test_wide_multi_rhs_sweeps(engine, cplx, n0, n1, nrhs, 256)
+    finally:
+        engine.set_tuning(30, 0)

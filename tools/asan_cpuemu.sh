@@ -10,7 +10,9 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 H=$R/tests/helpers
 CXX=/opt/rocm/lib/llvm/bin/clang++
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libasan -g -fno-omit-frame-pointer"
+# (-fno-sanitize=function: the engine calls librccl through pointers it declares itself -- ints for the enums, its own 128-byte struct for the
+# id -- and the stand-in of tests/helpers/hipcpu declares the same entry points with ITS types: the same C ABI, different C++ types)
+SAN="-fsanitize=address,undefined -fno-sanitize=function -fno-sanitize-recover=undefined -shared-libasan -g -fno-omit-frame-pointer"
 mkdir -p /tmp/asan_keep && cp $H/libmi355_cpuemu.so $H/libsched_emu.so /tmp/asan_keep/
 restore() { cp /tmp/asan_keep/libmi355_cpuemu.so /tmp/asan_keep/libsched_emu.so $H/; }
 trap restore EXIT
@@ -21,5 +23,5 @@ cd $R
 # (tests/test_cholmod_dropin.py is left out: it loads a library with RTLD_DEEPBIND, which the sanitizer runtime refuses)
 LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:halt_on_error=1 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-python -m pytest tests/test_abi_on_cpu.py tests/test_multi_abi.py tests/test_device_source_on_cpu.py tests/test_multigpu.py \
-    tests/test_schedule.py tests/test_fuzz_schedule.py -q -m "not gpu" -p no:cacheprovider "$@"
+python -m pytest ${ASAN_TESTS:-tests/test_abi_on_cpu.py tests/test_multi_abi.py tests/test_device_source_on_cpu.py tests/test_multigpu.py \
+    tests/test_schedule.py tests/test_fuzz_schedule.py tests/test_panel_groups.py} -q -m "not gpu" -p no:cacheprovider "$@"
