@@ -446,7 +446,12 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * right-hand sides (default 0 = off; 12 = on): inside a supernode of several solve groups the update of the rows beyond the
  * next group runs on a second stream beside the next group's kernel; the value is the number of CUs such a step leaves
  * to that kernel (read when the solve lists are built, at a factor's first solve).  Measured: - 2 .. 4 % for a real factor
- * with 64 right-hand sides, + 4 .. 5 % for a complex one or for 8 right-hand sides; keys 3 and 6: retired.  The values are
+ * with 64 right-hand sides, + 4 .. 5 % for a complex one or for 8 right-hand sides; key 31: the explicit inverse of a solve
+ * group's whole diagonal block (up to 256 x 256) for the steps of at most that many groups (default 4; 0 = off): such a step of the
+ * multi-RHS sweeps becomes ten independent 64 x 64 products on ten workgroups instead of a chain of ten dependent block steps on
+ * one (9 us instead of 20 .. 28 us per step of the top supernodes' chains); the inverses are built at the first solve after each
+ * factorization, by the chains themselves on the identity, and take 1 MB per group (2 MB complex); more than 4 groups per step
+ * measured slower than the chain; keys 3 and 6: retired.  The values are
  * process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 

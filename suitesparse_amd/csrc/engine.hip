@@ -97,6 +97,18 @@ struct DeviceSchedule {
     DevBuf<SolveGroupUpd> swtasks;
     DevBuf<int32_t> swwg;
     bool solve_groups_ready = false;
+    // ... explicit inverses of the groups' diagonal blocks for the steps of few groups (tuning key 31; k_solve_group_inv)
+    DevBuf<double> ginv;                // images of inv(L_g): row r of group g at (ginv_off[g] + r * 256) entries; the images of
+                                        // inv(L_g)^H (backward sweep) follow, ginv_rows * 256 entries further
+    DevBuf<int64_t> ginv_off;           // per group of ssched.groups; -1: none
+    DevBuf<SolveGroupTask> ginv_tasks;  // the groups that have one, x0 = first row of their image (for the chain that builds it)
+    DevBuf<double> ginv_scratch;        // k_solve_group_inv: a 256 x 16 tile per (group of a step, slab of 16 real columns), zero between launches
+    DevBuf<int> ginv_tickets;           // ... and its ticket
+    int64_t ginv_slots = 0;
+    std::vector<uint8_t> step_inv;      // per step of ssched.steps: every group of the step has an inverse
+    int64_t ginv_rows = 0;
+    uint64_t ginv_epoch = ~(uint64_t)0; // F->lx_epoch the images were built from
+    bool ginv_ready = false, ginv_off_for_good = false;
 };
 
 }  // namespace
@@ -146,6 +158,7 @@ struct mi355_factor_s {
     DevBuf<int64_t> Fp, Fi, Fnz;
     DevBuf<double> Fx;
     bool numeric_ok = false;    // a positive-definite factor is resident
+    uint64_t lx_epoch = 0;      // bumped whenever numeric_ok is assigned: what was derived from Lx / Dinv (the groups' inverses) is stale
     bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
     bool not_posdef = false;    // the last mi355_factor_numeric stopped at a bad pivot (L->minor < n)
     int64_t minor = 0;
@@ -1000,11 +1013,11 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
         }
         if (!hc->started) { hc.reset(); return fail(MI355_OUT_OF_MEMORY, "cannot start the copy threads"); }
     }
-    F->numeric_ok = false;
+    F->numeric_ok = false; F->lx_epoch++;
     F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
     if (S.n == 0 || S.nsuper == 0) {
-        F->minor = S.n; F->numeric_ok = true;
+        F->minor = S.n; F->numeric_ok = true; F->lx_epoch++;
         if (minor) *minor = S.n;
         if (status) *status = MI355_STATUS_OK;
         return MI355_OK;
@@ -1068,7 +1081,7 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
     F->st_total = ms;
     tm.pending = tm.on;
     F->minor = minor_out;
-    F->numeric_ok = (st_out == MI355_STATUS_OK);
+    F->numeric_ok = (st_out == MI355_STATUS_OK); F->lx_epoch++;
     F->not_posdef = (st_out == MI355_STATUS_NOT_POSDEF);
     if (minor) *minor = minor_out;
     if (status) *status = st_out;
@@ -1414,7 +1427,7 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
     if (phase != 0 && phase != 1) return fail(MI355_INVALID, "phase must be 0 (own subtrees) or 1 (top)");
     const Symbolic &S = F->sym;
-    F->numeric_ok = false;
+    F->numeric_ok = false; F->lx_epoch++;
     F->part_ok = false;
     if (first_bad) *first_bad = -1;
     if (info_out) *info_out = 0;
@@ -1578,6 +1591,85 @@ static int ensure_solve_groups(mi355_factor *F, DeviceSchedule &DS)
     return MI355_OK;
 }
 
+// Tuning key 31: the groups of the steps with at most that many groups get the explicit inverse of their diagonal block, so that
+// their step of the sweeps is one product (k_solve_group_inv) instead of a chain of ten.  Lists and memory once per schedule
+// (out of memory: the chain kernels stay, silently); the images again after every factorization, by the forward chain itself on
+// the identity as right-hand sides.
+static int ensure_group_inverses(mi355_factor *F, DeviceSchedule &DS, int nrr)
+{
+    constexpr int64_t W = SOLVE_GROUP * NB;
+    if (DS.ginv_off_for_good) return MI355_OK;
+    {
+        // scratch tiles and tickets for the widest step this call can launch: solve_group_inv groups x slabs of nrr
+        const int64_t slots = (int64_t)tuning().solve_group_inv * ((nrr + SG_CW - 1) / SG_CW);
+        if (slots > DS.ginv_slots) {
+            DS.ginv_slots = 0;
+            if (DS.ginv_scratch.alloc((size_t)slots * W * SG_CW) != hipSuccess || DS.ginv_tickets.alloc((size_t)slots) != hipSuccess) {
+                (void)hipGetLastError();
+                DS.ginv_scratch.release(); DS.ginv_tickets.release();
+                DS.ginv_off_for_good = true;
+                return MI355_OK;
+            }
+            HIP_TRY(hipMemsetAsync(DS.ginv_scratch.p, 0, (size_t)slots * W * SG_CW * sizeof(double), F->stream));
+            HIP_TRY(hipMemsetAsync(DS.ginv_tickets.p, 0, (size_t)slots * sizeof(int), F->stream));
+            DS.ginv_slots = slots;
+        }
+    }
+    if (!DS.ginv_ready) {
+        const SolveSchedule &ss = DS.ssched;
+        std::vector<int64_t> off(ss.groups.size(), -1);
+        std::vector<SolveGroupTask> tasks;
+        DS.step_inv.assign(ss.steps.size(), 0);
+        int64_t rows = 0;
+        for (size_t i = 0; i < ss.steps.size(); i++) {
+            const SolveStep &st = ss.steps[i];
+            if (st.gcount <= 0 || st.gcount > tuning().solve_group_inv || st.maxblk < 2) continue;
+            DS.step_inv[i] = 1;
+            for (int64_t g = st.gfirst; g < st.gfirst + st.gcount; g++) {
+                SolveGroupTask t = ss.groups[(size_t)g];
+                off[(size_t)g] = rows * W;
+                t.x0 = (int32_t)rows;
+                rows += t.ncols;
+                tasks.push_back(t);
+            }
+        }
+        if (tasks.empty() || rows > 0x7ffffff0LL) { DS.ginv_off_for_good = true; return MI355_OK; }
+        if (DS.ginv.alloc((size_t)2 * rows * W * F->E) != hipSuccess) {
+            (void)hipGetLastError();
+            DS.ginv_off_for_good = true;
+            return MI355_OK;
+        }
+        HIP_TRY(DS.ginv_off.upload(off.data(), off.size(), F->stream));
+        HIP_TRY(DS.ginv_tasks.upload(tasks.data(), tasks.size(), F->stream));
+        DS.ginv_rows = rows;
+        DS.ginv_ready = true;
+    }
+    if (DS.ginv_epoch != F->lx_epoch) {
+        const int64_t nt = (int64_t)DS.ginv_tasks.n;
+        const size_t half = (size_t)DS.ginv_rows * W * F->E;        // doubles of one set of images
+        HIP_TRY(hipMemsetAsync(DS.ginv.p, 0, 2 * half * sizeof(double), F->stream));
+        const dim3 g((unsigned)nt, (unsigned)(W * F->E / SG_CW));
+        if (F->E == 2) {
+            hipLaunchKernelGGL(k_ginv_identity<2>, dim3((unsigned)nt), dim3(256), 0, F->stream, DS.ginv_tasks.p, nt, DS.ginv.p);
+            hipLaunchKernelGGL(k_ginv_identity<2>, dim3((unsigned)nt), dim3(256), 0, F->stream, DS.ginv_tasks.p, nt, DS.ginv.p + half);
+            hipLaunchKernelGGL((k_solve_group_mma<false, 2, SOLVE_GROUP>), g, dim3(256), 0, F->stream,
+                               DS.ginv_tasks.p, F->Dinv.p, F->Lx.p, DS.ginv.p, W * 2, (int)(W * 2));
+            hipLaunchKernelGGL((k_solve_group_mma<true, 2, SOLVE_GROUP>), g, dim3(256), 0, F->stream,
+                               DS.ginv_tasks.p, F->Dinv.p, F->Lx.p, DS.ginv.p + half, W * 2, (int)(W * 2));
+        } else {
+            hipLaunchKernelGGL(k_ginv_identity<1>, dim3((unsigned)nt), dim3(256), 0, F->stream, DS.ginv_tasks.p, nt, DS.ginv.p);
+            hipLaunchKernelGGL(k_ginv_identity<1>, dim3((unsigned)nt), dim3(256), 0, F->stream, DS.ginv_tasks.p, nt, DS.ginv.p + half);
+            hipLaunchKernelGGL((k_solve_group_mma<false, 1, SOLVE_GROUP>), g, dim3(256), 0, F->stream,
+                               DS.ginv_tasks.p, F->Dinv.p, F->Lx.p, DS.ginv.p, W, (int)W);
+            hipLaunchKernelGGL((k_solve_group_mma<true, 1, SOLVE_GROUP>), g, dim3(256), 0, F->stream,
+                               DS.ginv_tasks.p, F->Dinv.p, F->Lx.p, DS.ginv.p + half, W, (int)W);
+        }
+        HIP_TRY(hipGetLastError());
+        DS.ginv_epoch = F->lx_epoch;
+    }
+    return MI355_OK;
+}
+
 // part == nullptr: the whole factor; else the sweeps over one masked schedule of a partitioned factor
 static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr)
 {
@@ -1673,6 +1765,9 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         // many right-hand sides, grouped: k_solve_group_mma per SOLVE_GROUP blocks + the MFMA updates of the rows below
         { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
         const std::vector<SolveStep> &gs = DS.ssched.steps;
+        // (the whole factor only: the partitioned sweeps run while other ranks' pieces of Lx and Dinv may still change)
+        const bool inv = tuning().solve_group_inv > 0 && part == nullptr;
+        if (inv) { const int rci = ensure_group_inverses(F, DS, nrr); if (rci) return rci; }
         // Look-ahead (tuning key 30; off by default -- measured below).  The top supernodes are chains of single-group steps: group kernel (a handful of
         // workgroups, ~20 us of dependent products) -> update of every row below (the whole chip) -> next group ...  Only the
         // first SOLVE_GROUP tiles of that update are rows of the NEXT group; the rest is needed two groups later at the
@@ -1719,7 +1814,19 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                 side_busy = false;
             }
             run = pos;
+            const size_t step_at = lower ? ii : gs.size() - 1 - ii;
             auto group_kernel = [&]() {
+                if (inv && DS.ginv_ready && !DS.ginv_off_for_good && DS.step_inv[step_at] &&
+                    st.gcount * ((nrr + SG_CW - 1) / SG_CW) <= DS.ginv_slots) {
+                    const dim3 g((unsigned)st.gcount, (unsigned)(10 * ((nrr + SG_CW - 1) / SG_CW))), b(256);
+#define MI355_SGI(T, EE) hipLaunchKernelGGL((k_solve_group_inv<T, EE>), g, b, 0, F->stream, DS.sgroups.p + st.gfirst, \
+                                            DS.ginv_off.p + st.gfirst, DS.ginv.p + (T ? (size_t)DS.ginv_rows * SOLVE_GROUP * NB * F->E : 0), X, d, nrr, \
+                                            DS.ginv_scratch.p, DS.ginv_tickets.p)
+                    if (lower) { if (cplx) MI355_SGI(false, 2); else MI355_SGI(false, 1); }
+                    else       { if (cplx) MI355_SGI(true, 2); else MI355_SGI(true, 1); }
+#undef MI355_SGI
+                    return;
+                }
                 // a step of one-block groups only (the leaf levels: 10^5 groups of a few columns) takes 64 real columns of Y per
                 // workgroup instead of 16: a quarter of the workgroups, each with four times the products of its one step
                 const int cw = (st.maxblk <= 1 && st.gcount >= 1024) ? 64 : SG_CW;
@@ -2251,6 +2358,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 28) tuning().panel_group = std::max(0, value);
     else if (key == 29) tuning().solve_wide_ring = value >= 3 ? 3 : 2;
     else if (key == 30) tuning().solve_lookahead = std::max(0, std::min(value, 128));
+    else if (key == 31) tuning().solve_group_inv = std::max(0, std::min(value, 4096));
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -644,7 +644,7 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
         rc = mi355_factor_numeric(F, beta_re, quick_return_if_not_posdef, minor, status);
         return rc;
     }
-    F->numeric_ok = false;
+    F->numeric_ok = false; F->lx_epoch++;
     F->part_ok = false;
     F->not_posdef = false;
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;

@@ -983,6 +983,123 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
 }
 
 //------------------------------------------------------------------------------
+// k_solve_group_inv (tuning key 31): the group's step of the sweeps as products with the explicit inverse of the group's whole
+// diagonal block, x1 <- inv(L_g) x1 or inv(L_g)^H x1, spread over ten workgroups.
+// Why: the group step is what the chain of the top supernodes is made of, and its time is the time ONE CU needs to fetch the
+// group's ten 64 x 64 blocks -- 320 KB at the ~25 GB/s a single CU draws = 13 of the ~19 us of k_solve_group_mma, whose ten block
+// steps depend on each other and so cannot leave their CU.  (Measured: the same products with the explicit inverse in ONE workgroup,
+// all loads independent, still took 18 us.)  With the inverse every product reads the ORIGINAL rows of Y, so each of the ten
+// (target block, source block) pairs goes to a workgroup of its own: 32 KB each.  The partial results meet in a zeroed scratch
+// tile per (group, slab of 16 real columns) by FP64 atomics; the workgroup that takes the last ticket of its tile copies the tile
+// over the group's rows of Y -- nobody reads those rows any more by then -- and leaves tile and ticket zeroed for the next launch.
+// No workgroup waits for another one.
+// The inverses are built once per factorization, at the first solve after it, by k_solve_group_mma itself on the identity as
+// right-hand sides (engine.hip, ensure_group_inverses): row-major images M[r * W + j], W = 256 entries per row (complex: (re, im)
+// pairs), rows r < ncols only, columns j >= ncols zero -- one of inv(L_g) for the forward sweep (lower triangular) and one of
+// inv(L_g)^H for the backward sweep (UPPER), so that both sweeps read their A operand along the rows of an image: a lane takes
+// 16 consecutive entries (the contraction index of a block is dealt k = 16 (lane / 16) + q, on both operands).
+// grid: (groups of the step, 10 block pairs per slab of SG_CW real columns); wave w owns rows [16w, 16w + 16) of the target block.
+//------------------------------------------------------------------------------
+template <bool UPPER, int E>
+__global__ __launch_bounds__(256) void k_solve_group_inv(
+    const SolveGroupTask *__restrict__ groups, const int64_t *__restrict__ ginv_off, const double *__restrict__ Ginv,
+    double *__restrict__ Y, int64_t ldr, int nrhs, double *__restrict__ scratch, int *__restrict__ tickets)
+{
+    constexpr int W = SOLVE_GROUP * NB, CW = SG_CW;
+    __shared__ double Ys[NB][CW + 2];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int ncols = groups[blockIdx.x].ncols, nblk = (ncols + NB - 1) / NB;
+    const int slab = blockIdx.y / 10, pair = blockIdx.y % 10;
+    const int c = sg_c(pair), b = sg_b(pair);                               // pair (c, b), b <= c < nblk
+    if (c >= nblk) return;                                                  // (uniform: the whole workgroup leaves, no ticket)
+    const int tt = UPPER ? b : c, ss = UPPER ? c : b;
+    double *__restrict__ y0 = Y + (int64_t)groups[blockIdx.x].x0 * ldr;
+    const double *__restrict__ G = Ginv + ginv_off[blockIdx.x] * E;
+    const int j0 = slab * CW, nj = min(CW, nrhs - j0);
+    const int64_t slot = (int64_t)blockIdx.x * (gridDim.y / 10) + slab;
+    double *__restrict__ S = scratch + slot * (W * CW);
+    // source rows of Y (block ss) -> LDS
+    {
+        constexpr int RS = 256 / CW;
+        const int j = tid % CW, rq = tid / CW;
+#pragma unroll
+        for (int i = 0; i < NB / RS; i++) {
+            const int r = NB * ss + rq + RS * i;
+            Ys[rq + RS * i][j] = (r < ncols && j < nj) ? y0[(int64_t)r * ldr + j0 + j] : 0.0;
+        }
+    }
+    // A operand: A[i][k], i = 16w + lane%16, k = 16 (lane/16) + q: entry (64 tt + i, 64 ss + k) of the image; rows of the image
+    // beyond ncols do not exist (address clamped, value zeroed)
+    double m[16 * E];
+    {
+        const int r = NB * tt + 16 * w + l15;
+        const double2 *__restrict__ p2 = reinterpret_cast<const double2 *>(G + ((int64_t)min(r, ncols - 1) * W + NB * ss + 16 * l4) * E);
+        const bool ok = r < ncols;
+        if constexpr (E == 2) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double2 v = p2[q];
+                m[q] = ok ? v.x : 0.0;
+                m[16 + q] = ok ? v.y : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q2 = 0; q2 < 8; q2++) {
+                const double2 v = p2[q2];
+                m[2 * q2] = ok ? v.x : 0.0;
+                m[2 * q2 + 1] = ok ? v.y : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const double *__restrict__ yr = &Ys[16 * l4 + q][0];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[q], yr[l15], acc, 0, 0, 0);
+        if constexpr (E == 2) {
+            const double v = yr[l15 ^ 1];                // Im(block) against the pair image, as in k_solve_group_mma
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[16 + q], (l15 & 1) ? v : -v, acc, 0, 0, 0);
+        }
+    }
+    // partial result: rows 64 tt + 16 w + lane/16 + 4 g of the tile, column lane%16
+#pragma unroll
+    for (int g = 0; g < 4; g++) atomic_add_f64(&S[(NB * tt + 16 * w + l4 + 4 * g) * CW + l15], acc[g]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&tickets[slot], 1) == nblk * (nblk + 1) / 2 - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // (plain loads: the tile was written by atomics only, which work at the L2; no line of it is in this CU's vector cache --
+    // the cache starts a launch empty and no workgroup reads the tile before this point.  All loads first: one round trip)
+    double2 v[W * CW / 512];
+#pragma unroll
+    for (int i = 0; i < W * CW / 512; i++) v[i] = reinterpret_cast<const double2 *>(S)[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < W * CW / 512; i++) {
+        const int idx = 2 * (tid + 256 * i), r = idx / CW, j = idx % CW;
+        reinterpret_cast<double2 *>(S)[tid + 256 * i] = make_double2(0.0, 0.0);
+        if (r < ncols && j < nj) y0[(int64_t)r * ldr + j0 + j] = v[i].x;
+        if (r < ncols && j + 1 < nj) y0[(int64_t)r * ldr + j0 + j + 1] = v[i].y;
+    }
+    if (tid == 0) tickets[slot] = 0;
+}
+
+// the identity as right-hand sides of the group chains that build the inverses: entry (r, r) of every image
+template <int E>
+__global__ __launch_bounds__(256) void k_ginv_identity(
+    const SolveGroupTask *__restrict__ tasks, int64_t ntasks, double *__restrict__ Ginv)
+{
+    constexpr int W = SOLVE_GROUP * NB;
+    const int64_t gi = blockIdx.x;
+    if (gi >= ntasks) return;
+    const int r = threadIdx.x;
+    if (r < tasks[gi].ncols) Ginv[(((int64_t)tasks[gi].x0 + r) * W + r) * E] = 1.0;
+}
+
+//------------------------------------------------------------------------------
 // k_panel_trsm (factorization, STEP_PTRSM): the rows below a panel group's diagonal window, X * L_w^T = A for the window's
 // <= 256 columns, in place.  Transposed, that is L_w * X^T = A^T: a forward solve with the window as the group and the
 // ROWS of the panel as right-hand sides -- and the column-major panel (column c of the window at c * nsrow, row r at + r)

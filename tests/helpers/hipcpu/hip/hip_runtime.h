@@ -89,6 +89,7 @@ inline v4d_t mfma_f64_16x16x4(double a, double b, v4d_t c)
     barrier_wait(&wav->bar);
     return c;
 }
+inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline double unsafeAtomicAdd(double *p, double v)
 {
     // workgroups run one after the other, the threads of one concurrently: a CAS loop keeps the add atomic
@@ -288,7 +289,7 @@ struct double2 { double x, y; };
 inline double2 make_double2(double x, double y) { double2 v; v.x = x; v.y = y; return v; }
 
 using hipcpu::threadIdx; using hipcpu::blockIdx; using hipcpu::blockDim; using hipcpu::gridDim;
-using hipcpu::unsafeAtomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
+using hipcpu::unsafeAtomicAdd; using hipcpu::atomicAdd; using hipcpu::atomicMin; using hipcpu::rsqrt;
 #define __global__
 #define __device__
 #define __host__

@@ -1036,3 +1036,46 @@ def test_sweeps_with_look_ahead(engine, cplx, n0, n1, nrhs, keep):
         test_wide_multi_rhs_sweeps(engine, cplx, n0, n1, nrhs, 256)
     finally:
         engine.set_tuning(30, 0)
+
+
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,most", [(False, 600, 150, 70, 4), (False, 1500, 400, 9, 64), (True, 300, 90, 7, 4), (True, 700, 100, 40, 1),
+                                                  (False, 330, 200, 20, 0), (False, 150, 100, 33, 4)])
+def test_group_steps_with_explicit_inverses(engine, cplx, n0, n1, nrhs, most):
+    """tuning key 31 (default 4): the steps of at most `most` solve groups run k_solve_group_inv -- ten independent products with
+    the explicit inverse of the group's 256 x 256 diagonal block, combined through a ticketed scratch tile -- instead of the chain
+    of k_solve_group_mma.  Ragged groups (330 = 256 + 74, 150 = 2 blocks + 22), real and complex, more right-hand sides than one
+    slab, the key off; and a SECOND factorization of other values on the same handle: the inverses are rebuilt (a stale image
+    would give the first matrix's answers)"""
+    from oracle import port
+    engine.set_tuning(31, most)
+    try:
+        test_wide_multi_rhs_sweeps(engine, cplx, n0, n1, nrhs, 256)
+        # the same structure, two sets of values on one handle
+        n = n0 + n1
+        extra = np.array(sorted(set(range(n0, n, 3)) | {n - 1}), dtype=np.int64)
+        rows0 = np.concatenate([np.arange(n0), extra])
+        sym = dict(n=n, nsuper=2, Super=np.array([0, n0, n]), Lpi=np.array([0, len(rows0), len(rows0) + n1]),
+                   Lpx=np.array([0, len(rows0) * n0, len(rows0) * n0 + n1 * n1]), Ls=np.concatenate([rows0, np.arange(n0, n)]))
+        sym["ssize"] = len(sym["Ls"]); sym["xsize"] = int(sym["Lpx"][-1]); sym["maxcsize"] = len(extra) ** 2
+        rng = np.random.default_rng(7 * n0 + nrhs)
+        rnd = (lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) if cplx else (lambda *sh: rng.standard_normal(sh))
+        import scipy.sparse as sp
+        L = engine.SupernodalFactor(sym, xtype=2 if cplx else 1)
+        B = rnd(n, nrhs)
+        for scale in (1.0, 3.0):
+            A = np.zeros((n, n), dtype=np.complex128 if cplx else np.float64)
+            A[np.ix_(rows0, np.arange(n0))] = rnd(len(rows0), n0) * scale
+            A[n0:, n0:] = rnd(n1, n1)
+            A = np.tril(A, -1)
+            A = A + A.conj().T
+            A += np.eye(n) * (np.abs(A).sum(1).max() + 1)
+            S = sp.csc_matrix(np.tril(A)); S.sort_indices()
+            Sp, Si, Sx = S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data
+            assert L.super_numeric(Sp, Si, Sx) == 0
+            so, mo, Lo = port.super_numeric(sym, Sp, Si, Sx)
+            Yo = port.super_solve(sym, Lo, B, lower=True)
+            assert relerr(L.super_lsolve(B), Yo) < 1e-10, scale
+            assert relerr(L.super_ltsolve(Yo), port.super_solve(sym, Lo, Yo, lower=False)) < 1e-10, scale
+        L.close()
+    finally:
+        engine.set_tuning(31, 4)
