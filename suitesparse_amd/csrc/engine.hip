@@ -1804,7 +1804,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                 HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                 F->solve_ev.push_back(ev);
             }
-        hipEvent_t *const evG = F->solve_ev.data(), *const evU = evG + 4;     // (only touched when look)
+        hipEvent_t *const evG = look ? F->solve_ev.data() : nullptr, *const evU = look ? evG + 4 : nullptr;
         int run = -1;                       // position of the previous step in its run; -1: it was not a split step
         int64_t run_next = -1;              // a_off of the group that continues the run
         int32_t run_lda = 0;
