@@ -9,7 +9,7 @@ txt=open(sys.argv[1]).read()
 blocks=re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
 out=[]
 out.append("# Static resource usage of every kernel in libmi355_cholmod.so (hipcc --offload-arch=gfx950 -O3, ROCm 7.2.0,")
-out.append("# -Rpass-analysis=kernel-resource-usage; round 2).  No GPU is needed for this table.")
+out.append("# -Rpass-analysis=kernel-resource-usage; round 3).  No GPU is needed for this table.")
 out.append(f"{'kernel':72s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch B/lane':>15s} {'waves/SIMD':>11s} {'LDS B/WG':>9s}")
 K=[r"VGPRs", r"AGPRs", r"SGPRs", r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]", r"LDS Size \[bytes/block\]"]
 for b in blocks:
