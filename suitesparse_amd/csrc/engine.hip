@@ -1671,7 +1671,9 @@ static int ensure_group_inverses(mi355_factor *F, DeviceSchedule &DS, int nrr)
 }
 
 // part == nullptr: the whole factor; else the sweeps over one masked schedule of a partitioned factor
-static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr)
+// image (many right-hand sides only): 1 = the row-major image in F->Yrow already holds the right-hand sides (the sweep before left
+// it there), 2 = leave the result in the image -- a forward + backward solve (sys A, LDLt) transposes once in and once out
+static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64_t d, DeviceSchedule *part = nullptr, int image = 0)
 {
     const Symbolic &S = F->sym;
     if (nrhs < 0 || d < S.n) return fail(MI355_INVALID, "X and L dimensions must match");
@@ -1760,13 +1762,16 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         const int64_t ldr = ((int64_t)nrr + 15) & ~(int64_t)15;
         const size_t need = (size_t)S.n * (size_t)ldr;
         if (need > F->yrow_cap) {
+            if (image & 1) return fail(MI355_GPU_PROBLEM, "internal: no image of the right-hand sides to continue on");
             F->Yrow.release();
             F->yrow_cap = 0;
             HIP_TRY(F->Yrow.alloc(need));
             F->yrow_cap = need;
         }
         const unsigned tg = (unsigned)((S.n + 63) / 64);
-        if (cplx)
+        if (image & 1) {
+            // the forward sweep left its result in the image
+        } else if (cplx)
             hipLaunchKernelGGL(k_solve_transpose<double2>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
                                reinterpret_cast<double2 *>(Xcol), dcol, reinterpret_cast<double2 *>(F->Yrow.p), ldr / 2, 1);
         else
@@ -2037,7 +2042,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             HIP_TRY(hipGetLastError());
         }
     }
-    if (mma) {
+    if (mma && !(image & 2)) {
         const unsigned tg = (unsigned)((S.n + 63) / 64);
         if (cplx)
             hipLaunchKernelGGL(k_solve_transpose<double2>, dim3(tg), dim3(256), 0, F->stream, S.n, nr,
@@ -2240,8 +2245,9 @@ int mi355_solve_x_dev(mi355_factor *F, int sys, int64_t nrhs, int bxtype, const 
     double ms = 0;
     const bool fwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_L || sys == MI355_SYS_LD);
     const bool bwd = (sys == MI355_SYS_A || sys == MI355_SYS_LDLt || sys == MI355_SYS_Lt || sys == MI355_SYS_DLt);
-    if (fwd) { rc = solve_dev(F, true, nry, Y, n); if (rc) return rc; ms += F->st_solve; }
-    if (bwd) { rc = solve_dev(F, false, nry, Y, n); if (rc) return rc; ms += F->st_solve; }
+    // (both sweeps: the row-major image of the many-RHS path stays in place between them; the flags mean nothing to the other paths)
+    if (fwd) { rc = solve_dev(F, true, nry, Y, n, nullptr, bwd ? 2 : 0); if (rc) return rc; ms += F->st_solve; }
+    if (bwd) { rc = solve_dev(F, false, nry, Y, n, nullptr, fwd ? 1 : 0); if (rc) return rc; ms += F->st_solve; }
     F->st_solve = ms;
     const int64_t *sperm = (sys == MI355_SYS_A || sys == MI355_SYS_Pt) ? perm : nullptr;     // X = P'*Y, or X = Y
     hipLaunchKernelGGL(k_permute_rows, dim3(grid), dim3(256), 0, F->stream, n, nr, sperm,
