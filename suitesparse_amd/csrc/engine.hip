@@ -1702,10 +1702,10 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         // few right-hand sides: the sweep is a chain of dependent launches -- two per SOLVE_GROUP blocks
         { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
         const std::vector<SolveStep> &gs = DS.ssched.steps;
-        // one right-hand side: a column of X is its own row-major image (ldr = 1), so the steps of few groups take the explicit
-        // inverses here too (k_solve_group_inv with one slab that holds one column)
-        const bool inv = tuning().solve_group_inv > 0 && part == nullptr && nr == 1;
-        if (inv) { const int rci = ensure_group_inverses(F, DS, 1); if (rci) return rci; }
+        // a column of X is its own row-major image (ldr = 1), so the steps of few groups take the explicit inverses here too
+        // (k_solve_group_inv with one slab per column)
+        const bool inv = tuning().solve_group_inv > 0 && part == nullptr;
+        if (inv) { const int rci = ensure_group_inverses(F, DS, SG_CW * nr); if (rci) return rci; }      // (nr slabs of one column)
         for (size_t ii = 0; ii < gs.size(); ii++) {
             const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
             if (st.gcount <= 0) continue;
@@ -1714,14 +1714,14 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
             auto group_kernel = [&]() {
                 const dim3 g((unsigned)st.gcount), b(256);
                 const SolveGroupTask *gp = DS.sgroups.p + st.gfirst;
-                if (inv && DS.ginv_ready && !DS.ginv_off_for_good && DS.step_inv[step_at] && st.gcount <= DS.ginv_slots) {
-                    const dim3 gi((unsigned)st.gcount, 10);
+                if (inv && DS.ginv_ready && !DS.ginv_off_for_good && DS.step_inv[step_at] && st.gcount * nr <= DS.ginv_slots) {
+                    const dim3 gi((unsigned)st.gcount, (unsigned)(10 * nr));
                     if (lower)
                         hipLaunchKernelGGL((k_solve_group_inv<false, 1>), gi, b, 0, F->stream, gp, DS.ginv_off.p + st.gfirst, DS.ginv.p,
-                                           X, (int64_t)1, 1, DS.ginv_scratch.p, DS.ginv_tickets.p);
+                                           X, (int64_t)1, nr, DS.ginv_scratch.p, DS.ginv_tickets.p, 1, d);
                     else
                         hipLaunchKernelGGL((k_solve_group_inv<true, 1>), gi, b, 0, F->stream, gp, DS.ginv_off.p + st.gfirst,
-                                           DS.ginv.p + (size_t)DS.ginv_rows * SOLVE_GROUP * NB, X, (int64_t)1, 1, DS.ginv_scratch.p, DS.ginv_tickets.p);
+                                           DS.ginv.p + (size_t)DS.ginv_rows * SOLVE_GROUP * NB, X, (int64_t)1, nr, DS.ginv_scratch.p, DS.ginv_tickets.p, 1, d);
                     return;
                 }
 #define MI355_SG(T, NRT, MB) hipLaunchKernelGGL((k_solve_group<T, NRT, MB>), g, b, 0, F->stream, gp, F->Dinv.p, F->Lx.p, X, d, nr)
@@ -1841,7 +1841,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
                     const dim3 g((unsigned)st.gcount, (unsigned)(10 * ((nrr + SG_CW - 1) / SG_CW))), b(256);
 #define MI355_SGI(T, EE) hipLaunchKernelGGL((k_solve_group_inv<T, EE>), g, b, 0, F->stream, DS.sgroups.p + st.gfirst, \
                                             DS.ginv_off.p + st.gfirst, DS.ginv.p + (T ? (size_t)DS.ginv_rows * SOLVE_GROUP * NB * F->E : 0), X, d, nrr, \
-                                            DS.ginv_scratch.p, DS.ginv_tickets.p)
+                                            DS.ginv_scratch.p, DS.ginv_tickets.p, SG_CW, (int64_t)SG_CW)
                     if (lower) { if (cplx) MI355_SGI(false, 2); else MI355_SGI(false, 1); }
                     else       { if (cplx) MI355_SGI(true, 2); else MI355_SGI(true, 1); }
 #undef MI355_SGI

@@ -1003,8 +1003,11 @@ __global__ __launch_bounds__(256) void k_solve_group_mma(
 template <bool UPPER, int E>
 __global__ __launch_bounds__(256) void k_solve_group_inv(
     const SolveGroupTask *__restrict__ groups, const int64_t *__restrict__ ginv_off, const double *__restrict__ Ginv,
-    double *__restrict__ Y, int64_t ldr, int nrhs, double *__restrict__ scratch, int *__restrict__ tickets)
+    double *__restrict__ Y, int64_t ldr, int nrhs, double *__restrict__ scratch, int *__restrict__ tickets,
+    int slab_cols, int64_t slab_stride)
 {
+    // slab_cols / slab_stride: columns of Y per slab and the distance between two slabs -- SG_CW and SG_CW on the row-major image;
+    // 1 and the leading dimension for a few COLUMN-major right-hand sides (ldr = 1: a slab is one column, a sixteenth of the products)
     constexpr int W = SOLVE_GROUP * NB, CW = SG_CW;
     __shared__ double Ys[NB][CW + 2];
     __shared__ int last;
@@ -1016,7 +1019,8 @@ __global__ __launch_bounds__(256) void k_solve_group_inv(
     const int tt = UPPER ? b : c, ss = UPPER ? c : b;
     double *__restrict__ y0 = Y + (int64_t)groups[blockIdx.x].x0 * ldr;
     const double *__restrict__ G = Ginv + ginv_off[blockIdx.x] * E;
-    const int j0 = slab * CW, nj = min(CW, nrhs - j0);
+    const int64_t j0 = (int64_t)slab * slab_stride;
+    const int nj = min(slab_cols, nrhs - slab * slab_cols);
     const int64_t slot = (int64_t)blockIdx.x * (gridDim.y / 10) + slab;
     double *__restrict__ S = scratch + slot * (W * CW);
     // source rows of Y (block ss) -> LDS

@@ -564,7 +564,8 @@ def test_sweeps_with_look_ahead_through_the_abi(engine, cplx, n0, n1, nrhs, keep
     t.test_sweeps_with_look_ahead(engine, cplx, n0, n1, nrhs, keep)
 
 
-@pytest.mark.parametrize("cplx,n0,n1,nrhs,most", [(False, 600, 150, 20, 4), (True, 300, 90, 7, 4), (False, 330, 100, 9, 0)])
+@pytest.mark.parametrize("cplx,n0,n1,nrhs,most", [(False, 600, 150, 20, 4), (True, 300, 90, 7, 4), (False, 330, 100, 9, 0), (False, 600, 150, 3, 4),
+                                                  (False, 330, 90, 1, 4)])
 def test_group_steps_with_explicit_inverses_through_the_abi(engine, cplx, n0, n1, nrhs, most):
     """tuning key 31: k_solve_group_inv, k_ginv_identity and the rebuild after a second factorization, from their own source"""
     import test_gpu_parity as t

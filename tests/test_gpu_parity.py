@@ -1039,12 +1039,13 @@ def test_sweeps_with_look_ahead(engine, cplx, n0, n1, nrhs, keep):
 
 
 @pytest.mark.parametrize("cplx,n0,n1,nrhs,most", [(False, 600, 150, 70, 4), (False, 1500, 400, 9, 64), (True, 300, 90, 7, 4), (True, 700, 100, 40, 1),
-                                                  (False, 330, 200, 20, 0), (False, 150, 100, 33, 4)])
+                                                  (False, 330, 200, 20, 0), (False, 150, 100, 33, 4), (False, 600, 150, 3, 4), (False, 330, 90, 1, 4),
+                                                  (False, 700, 100, 4, 2)])
 def test_group_steps_with_explicit_inverses(engine, cplx, n0, n1, nrhs, most):
     """tuning key 31 (default 4): the steps of at most `most` solve groups run k_solve_group_inv -- ten independent products with
     the explicit inverse of the group's 256 x 256 diagonal block, combined through a ticketed scratch tile -- instead of the chain
     of k_solve_group_mma.  Ragged groups (330 = 256 + 74, 150 = 2 blocks + 22), real and complex, more right-hand sides than one
-    slab, the key off; and a SECOND factorization of other values on the same handle: the inverses are rebuilt (a stale image
+    slab, 1 .. 4 column-major right-hand sides (the scalar sweeps: one slab per column), the key off; and a SECOND factorization of other values on the same handle: the inverses are rebuilt (a stale image
     would give the first matrix's answers)"""
     from oracle import port
     engine.set_tuning(31, most)
