@@ -719,7 +719,10 @@ def test_every_allocation_failure_falls_back_to_the_cpu(name):
             k += 1
     finally:
         emu.hipcpu_fail_alloc_at(0)
-    assert k > 10 and fell_back >= k - 2, (k, fell_back)     # every injected failure ended in a fallback, none in an error
+    # every injected failure ended in a fallback, none in an error -- except the three allocations of the solve that are optional
+    # (the explicit inverses of the solve groups, their scratch tiles and tickets: engine.hip, ensure_group_inverses): without them
+    # the sweeps run the chain kernels and the run above still had to give the reference's solution
+    assert k > 10 and fell_back >= k - 2 - 3, (k, fell_back)
 
 
 @pytest.mark.parametrize("name,world", [("lap3d_8_metis", 2), ("helm3d_6_metis", 3), ("lap2d_16_npd0", 2)])
