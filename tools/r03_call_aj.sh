@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 3, GPU call AJ: PTRSM with two row tiles per wave (key 32 = 2, rows per workgroup 128): parity of the panel-group tests
+# (the variant was taken back after this call -- profiles/r03_tile_knobs_final_kernels.txt; key 32 no longer exists, the script is kept as the record of what ran)
 # with it, then the 150^3 factorization with key 28 = 64 (default) / 128 / 128 + key 32 = 2, and the kernel's time from a trace
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03aj; rm -rf $O; mkdir -p $O
 cd $R
