@@ -451,7 +451,9 @@ int mi355_debug_gemm_rate(int device, int kernel, int M, int N, int K, int iters
  * multi-RHS sweeps becomes ten independent 64 x 64 products on ten workgroups instead of a chain of ten dependent block steps on
  * one (9 us instead of 20 .. 28 us per step of the top supernodes' chains); the inverses are built at the first solve after each
  * factorization, by the chains themselves on the identity, and take 1 MB per group (2 MB complex); more than 4 groups per step
- * measured slower than the chain; keys 3 and 6: retired.  The values are
+ * measured slower than the chain; key 33 (default 1; 0 = off): a step of the wide sweeps whose
+ * tiles, cut to 64 (or 128) columns per task, still fit one round of workgroups is cut that way -- a workgroup then fetches a
+ * quarter of the x image and of L (measured - 0.5 .. 1.7 % of a 64-RHS solve); keys 3 and 6: retired.  The values are
  * process-wide and read when a factor is created. */
 int mi355_set_tuning(int key, int value);
 

@@ -2380,6 +2380,7 @@ int mi355_set_tuning(int key, int value)
     else if (key == 29) tuning().solve_wide_ring = value >= 3 ? 3 : 2;
     else if (key == 30) tuning().solve_lookahead = std::max(0, std::min(value, 128));
     else if (key == 31) tuning().solve_group_inv = std::max(0, std::min(value, 4096));
+    else if (key == 33) tuning().solve_wide_ksplit = value ? 1 : 0;
     else return fail(MI355_INVALID, "unknown tuning key");
     return MI355_OK;
 }

@@ -720,6 +720,23 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                     blocks[(size_t)(gi - st.gfirst)].push_back(pt);
                 }
             }
+            // Contraction depth of this step's wide tasks (tuning key 33).  A workgroup of the wide kernels fetches the x image of
+            // its task (ncols x 64 right-hand sides: 128 KB at 256 columns) and its tiles of L (128 KB each), and ONE CU draws
+            // ~25 GB/s: a step of few tiles -- the tail of every supernode's chain -- is bound by that fetch, not by the chip.
+            // Such a step is cut along the columns too (64 or 128 per task) while its tiles still fit one round of workgroups.
+            int kstep = kmax;
+            if (kmax > NB && tuning().solve_wide_ksplit > 0) {
+                int64_t pre = 0;
+                for (int64_t gi = 0; gi < st.gcount; gi++) {
+                    const SolveGroupTask &gt = out.groups[(size_t)(st.gfirst + gi)];
+                    if (gt.ncols <= NB || blocks[(size_t)gi].empty()) continue;
+                    const PotrfTask &p0 = blocks[(size_t)gi][0];
+                    const int64_t below = (int64_t)p0.lda - ((gt.x0 - p0.k1) + gt.ncols);
+                    if (below > 0) pre += (below + SOLVE_ROWS - 1) / SOLVE_ROWS * ((gt.ncols + NB - 1) / NB);   // tiles at 64 columns per task
+                }
+                if (pre > 0 && pre <= tuning().solve_wide_wgs) kstep = NB;
+                else if (pre > 0 && pre <= 2 * (int64_t)tuning().solve_wide_wgs && kmax > 2 * NB) kstep = 2 * NB;
+            }
             for (int64_t gi = 0; gi < st.gcount; gi++) {
                 const SolveGroupTask &gt = out.groups[(size_t)(st.gfirst + gi)];
                 // look-ahead (tuning key 30): a step of ONE group with rows beyond the next group's is split -- the first
@@ -761,10 +778,10 @@ void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax)
                     const int32_t gcol0 = gt.x0 - p0.k1;
                     const int32_t skip = near_tiles * SOLVE_ROWS;       // rows of a split step that the per-block lists hold
                     const int32_t below = p0.lda - (gcol0 + gt.ncols) - skip;
-                    for (int32_t c0 = 0; below > 0 && c0 < gt.ncols; c0 += kmax) {
+                    for (int32_t c0 = 0; below > 0 && c0 < gt.ncols; c0 += kstep) {
                         SolveGroupUpd wt;
                         wt.lda = p0.lda;
-                        wt.ncols = std::min<int32_t>(kmax, gt.ncols - c0);
+                        wt.ncols = std::min<int32_t>(kstep, gt.ncols - c0);
                         wt.x0 = gt.x0 + c0;
                         wt.nrows = below;
                         // gt.a_off = L[gcol0][gcol0]; the first row below the group is local row gcol0 + ncols

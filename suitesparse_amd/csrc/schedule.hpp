@@ -282,7 +282,7 @@ struct Schedule;
 void build_solve_groups(const Schedule &sc, SolveSchedule &out, int kmax = 0 /* 256 real, 128 complex; 0: no wide lists */);
 
 // tasks at least this large go to the big-tile (BTILE) kernel; settable for experiments
-struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; int panel_group = 64; int solve_wide_ring = 2; int solve_lookahead = 0; int solve_group_inv = 4; };
+struct Tuning { int big_min_m = 192; int big_min_n = 96; int ob = 256; int supertile = 8; int xcd_deal = 0; int ob2 = 1024; int ob3 = 0; int solve_mma_min = 5; int solve_mma_min_c = 3; int solve_group = 1; int solve_bwd_div = 256; int solve_bwd_div_mma = 4096; int solve_fwd_div_mma = 4096; int lookahead = 0; int tiny_max = 2048; int dist_lookahead = 1; int dist_pieces = 1; int host_chunk = 32 << 20; int dist_reduce_channel = 0; int host_lanes = 4; int host_lane_mb = 32; int host_staged_min_kb = 4096; int solve_wide = 1; int solve_wide_wgs = 256; int solve_wide_1024 = 0; int fuse_potrf = 0; int deterministic = 0; int panel_group = 64; int solve_wide_ring = 2; int solve_lookahead = 0; int solve_group_inv = 4; int solve_wide_ksplit = 1; };
 Tuning &tuning();
 void append_tiles(std::vector<Schedule::TileEntry> &seq, int32_t task, const GemmTask &t, int tile_m, int tile_n);
 void deal_tiles(const std::vector<Schedule::TileEntry> &seq, std::vector<Schedule::TileEntry> &tab);

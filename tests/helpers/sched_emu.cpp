@@ -303,6 +303,7 @@ void emu_set_tuning(int key, int value)
     else if (key == 27) tuning().deterministic = value;
     else if (key == 28) tuning().panel_group = value;
     else if (key == 30) tuning().solve_lookahead = value;
+    else if (key == 33) tuning().solve_wide_ksplit = value;
     else if (key == 100) hostrun::use_device_source = value;    // run the product's host-runnable kernels
 }
 
