@@ -158,7 +158,7 @@ struct mi355_factor_s {
     DevBuf<int64_t> Fp, Fi, Fnz;
     DevBuf<double> Fx;
     bool numeric_ok = false;    // a positive-definite factor is resident
-    uint64_t lx_epoch = 0;      // bumped whenever numeric_ok is assigned: what was derived from Lx / Dinv (the groups' inverses) is stale
+    uint64_t lx_epoch = 0;      // bumped whenever numeric_ok or part_ok is assigned: what was derived from Lx / Dinv (the groups' inverses) is stale
     bool part_ok = false;       // ... through the two partition phases (own subtrees + top)
     bool not_posdef = false;    // the last mi355_factor_numeric stopped at a bad pivot (L->minor < n)
     int64_t minor = 0;
@@ -1013,8 +1013,8 @@ int numeric_impl(mi355_factor *F, double beta_re, int quick_return_if_not_posdef
         }
         if (!hc->started) { hc.reset(); return fail(MI355_OUT_OF_MEMORY, "cannot start the copy threads"); }
     }
-    F->numeric_ok = false; F->lx_epoch++;
-    F->part_ok = false;         // whatever a partitioned run left in Lx is overwritten from here on
+    F->numeric_ok = false;
+    F->part_ok = false; F->lx_epoch++;         // whatever a partitioned run left in Lx is overwritten from here on
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
     if (S.n == 0 || S.nsuper == 0) {
         F->minor = S.n; F->numeric_ok = true; F->lx_epoch++;
@@ -1409,7 +1409,7 @@ int mi355_factor_set_partition(mi355_factor *F, const int8_t *local_mask, const 
     build_schedule(S, S.nsuper, 0, F->part_local->sched, local_mask);
     // the top's block inverses sit behind the own subtrees' in Dinv: the solve phases need both
     build_schedule(S, S.nsuper, 0, F->part_top->sched, top_mask, F->part_local->sched.dinv_size);
-    F->part_ok = false;
+    F->part_ok = false; F->lx_epoch++;
     rc = upload_schedule(F, *F->part_local);
     if (rc) return rc;
     rc = upload_schedule(F, *F->part_top);
@@ -1427,8 +1427,8 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
     if (!F->have_A) return fail(MI355_INVALID, "mi355_factor_set_matrix was not called");
     if (phase != 0 && phase != 1) return fail(MI355_INVALID, "phase must be 0 (own subtrees) or 1 (top)");
     const Symbolic &S = F->sym;
-    F->numeric_ok = false; F->lx_epoch++;
-    F->part_ok = false;
+    F->numeric_ok = false;
+    F->part_ok = false; F->lx_epoch++;
     if (first_bad) *first_bad = -1;
     if (info_out) *info_out = 0;
     if (S.nsuper == 0) return MI355_OK;
@@ -1461,7 +1461,7 @@ int mi355_factor_numeric_phase(mi355_factor *F, int phase, double beta_re, int64
         if (first_bad) *first_bad = sf;
         if (info_out) *info_out = info;
     } else if (phase == 1) {
-        F->part_ok = true;      // the caller vouches for phase 0 (on every rank) having succeeded
+        F->part_ok = true; F->lx_epoch++;      // the caller vouches for phase 0 (on every rank) having succeeded
     }
     return MI355_OK;
 }
@@ -1480,7 +1480,7 @@ int mi355_factor_set_top_distribution(mi355_factor *F, int rank, int world)
     build_schedule(S, S.nsuper, 0, F->part_dist->sched, F->top_mask_host.data(), F->part_local->sched.dinv_size, &dt);
     if (F->part_dist->sched.dinv_size != F->part_top->sched.dinv_size)
         return fail(MI355_GPU_PROBLEM, "internal: Dinv slots of the distributed top differ from the replicated top's");
-    F->part_ok = false;
+    F->part_ok = false; F->lx_epoch++;
     return upload_schedule(F, *F->part_dist);
 }
 
@@ -1517,7 +1517,7 @@ int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64
     if (seg < 0 || seg > nb) return fail(MI355_INVALID, "segment out of range");
     if (first_bad) *first_bad = -1;
     if (info_out) *info_out = 0;
-    F->part_ok = false;
+    F->part_ok = false; F->lx_epoch++;
     if (S.nsuper == 0) return MI355_OK;
     if (!F->timer) F->timer = new EventTimer;
     EventTimer &tm = *F->timer;
@@ -1557,7 +1557,7 @@ int mi355_factor_top_run(mi355_factor *F, int64_t seg, int64_t *first_bad, int64
             if (first_bad) *first_bad = sf;
             if (info_out) *info_out = info;
         } else {
-            F->part_ok = true;  // the caller vouches for every rank having succeeded (and for the Dinv sum)
+            F->part_ok = true; F->lx_epoch++;  // the caller vouches for every rank having succeeded (and for the Dinv sum)
         }
     }
     return MI355_OK;
@@ -1704,7 +1704,7 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         const std::vector<SolveStep> &gs = DS.ssched.steps;
         // a column of X is its own row-major image (ldr = 1), so the steps of few groups take the explicit inverses here too
         // (k_solve_group_inv with one slab per column)
-        const bool inv = tuning().solve_group_inv > 0 && part == nullptr;
+        const bool inv = tuning().solve_group_inv > 0;
         if (inv) { const int rci = ensure_group_inverses(F, DS, SG_CW * nr); if (rci) return rci; }      // (nr slabs of one column)
         for (size_t ii = 0; ii < gs.size(); ii++) {
             const SolveStep &st = gs[lower ? ii : gs.size() - 1 - ii];
@@ -1785,8 +1785,9 @@ static int solve_dev(mi355_factor *F, bool lower, int64_t nrhs, double *X, int64
         // many right-hand sides, grouped: k_solve_group_mma per SOLVE_GROUP blocks + the MFMA updates of the rows below
         { const int rcg = ensure_solve_groups(F, DS); if (rcg) return rcg; }
         const std::vector<SolveStep> &gs = DS.ssched.steps;
-        // (the whole factor only: the partitioned sweeps run while other ranks' pieces of Lx and Dinv may still change)
-        const bool inv = tuning().solve_group_inv > 0 && part == nullptr;
+        // (a partitioned factor too: part_ok says that every piece of Lx and Dinv this schedule reads is final, and whatever
+        // assigns it bumps lx_epoch; the images belong to the schedule -- own subtrees and top have their own)
+        const bool inv = tuning().solve_group_inv > 0;
         if (inv) { const int rci = ensure_group_inverses(F, DS, nrr); if (rci) return rci; }
         // Look-ahead (tuning key 30; off by default -- measured below).  The top supernodes are chains of single-group steps: group kernel (a handful of
         // workgroups, ~20 us of dependent products) -> update of every row below (the whole chip) -> next group ...  Only the

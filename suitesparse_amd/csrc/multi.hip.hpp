@@ -644,8 +644,8 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
         rc = mi355_factor_numeric(F, beta_re, quick_return_if_not_posdef, minor, status);
         return rc;
     }
-    F->numeric_ok = false; F->lx_epoch++;
-    F->part_ok = false;
+    F->numeric_ok = false;
+    F->part_ok = false; F->lx_epoch++;
     F->not_posdef = false;
     F->st_ngemm = F->st_npotrf = F->st_tiles = F->st_nbig = 0;
     if (!F->timer) F->timer = new EventTimer;
@@ -887,7 +887,7 @@ int mi355_factor_numeric_multi(mi355_factor *F, mi355_comm *c, double beta_re, i
     F->st_total = ms;
     tm.pending = tm.on;
     F->minor = S.n;
-    F->part_ok = true;
+    F->part_ok = true; F->lx_epoch++;
     if (minor) *minor = S.n;
     if (status) *status = MI355_STATUS_OK;
     return MI355_OK;
